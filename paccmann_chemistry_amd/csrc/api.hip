@@ -1,0 +1,814 @@
+// C ABI drivers: enqueue the kernels of one call on the caller's stream.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "stackgru.h"
+
+int pcm_launch_dropout_add(float *dst, long long ldd, const float *src,
+                           long long lds_, int B, int H, uint64_t seed,
+                           int layer, int t, float p, hipStream_t stream);
+int pcm_launch_choose(const float *logits, int B, int V, int search,
+                      float temperature, uint64_t seed, int step,
+                      int64_t *next_tok, int64_t *tokens_out,
+                      long long out_stride, int out_col, hipStream_t stream);
+int pcm_launch_broadcast_token(const int64_t *src, int B, int64_t *next_tok,
+                               int64_t *tokens_out, long long out_stride,
+                               int out_col, hipStream_t stream);
+
+// ---- errors -----------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void pcm_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int pcm_check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        pcm_set_error("%s: %s", what, hipGetErrorString(e));
+        return PCM_EDEVICE;
+    }
+    return PCM_OK;
+}
+
+// ---- layouts ----------------------------------------------------------------------
+static size_t take(size_t &off, size_t n) {
+    size_t at = off;
+    off += (size_t)pcm_round_up((int64_t)n, 64);
+    return at;
+}
+
+static int check_dims(const pcm_dims *d) {
+    PCM_REQUIRE(d, PCM_EINVAL, "dims is null");
+    PCM_REQUIRE(d->batch > 0 && d->vocab > 0 && d->emb > 0 && d->hidden > 0,
+                PCM_EINVAL, "dims: B=%d V=%d E=%d H=%d must be positive",
+                d->batch, d->vocab, d->emb, d->hidden);
+    PCM_REQUIRE(d->layers >= 1 && d->layers <= PCM_MAX_LAYERS, PCM_EINVAL,
+                "dims: layers=%d outside 1..%d", d->layers, PCM_MAX_LAYERS);
+    PCM_REQUIRE(!d->use_stack || (d->stack_depth >= 1 && d->stack_width >= 1),
+                PCM_EINVAL, "dims: stack %dx%d must be positive",
+                d->stack_depth, d->stack_width);
+    return PCM_OK;
+}
+
+int pcm_sg_layout(const pcm_dims *d, int steps, int training, int dropout,
+                  SGLayout *o) {
+    int rc = check_dims(d);
+    if (rc) return rc;
+    PCM_REQUIRE(steps >= 1, PCM_EINVAL, "steps=%d must be >= 1", steps);
+    memset(o, 0, sizeof(*o));
+    o->B = d->batch; o->V = d->vocab; o->E = d->emb; o->H = d->hidden;
+    o->L = d->layers; o->use_stack = d->use_stack ? 1 : 0;
+    o->D = o->use_stack ? d->stack_depth : 0;
+    o->W = o->use_stack ? d->stack_width : 0;
+    o->T = steps; o->training = training ? 1 : 0;
+    o->dropout = (training && dropout) ? 1 : 0;
+    o->Hp = (int)pcm_round_up(o->H, 64);
+    o->Hn = (int)pcm_round_up(o->H, 32);
+    o->Wp = o->use_stack ? (int)pcm_round_up(o->W, 64) : 0;
+    o->AVW = o->use_stack ? (int)pcm_round_up(3 + o->W, 4) : 0;
+    o->DW = o->D * o->W;
+    size_t off = 0;
+    const size_t BH = (size_t)o->B * o->Hp;
+    for (int l = 0; l < o->L; ++l) {
+        o->Kx[l] = l == 0 ? o->W : o->H;
+        o->Kxp[l] = l == 0 ? o->Wp : o->Hp;
+        o->Kp[l] = o->Kxp[l] + o->Hp;
+        o->off_hs[l] = take(off, (size_t)(steps + 1) * BH);
+    }
+    for (int l = 1; l < o->L; ++l)
+        if (o->dropout) o->off_xdrop[l] = take(off, (size_t)steps * BH);
+    if (o->training)
+        for (int l = 0; l < o->L; ++l)
+            o->off_gates[l] = take(off, (size_t)steps * o->B * 4 * o->H);
+    if (o->use_stack) {
+        const size_t slots = o->training ? steps + 1 : 2;
+        const size_t per = o->training ? steps : 1;
+        o->off_S = take(off, slots * o->B * o->DW);
+        o->off_av = take(off, per * o->B * o->AVW);
+        o->off_xtop = take(off, per * o->B * o->Wp);
+    }
+    o->off_tokg = take(off, (size_t)o->V * 3 * o->Hn);
+    for (int l = 0; l < o->L; ++l) {
+        o->off_wpack[l] = take(off, (size_t)3 * o->Hn * o->Kp[l]);
+        o->off_bpack[l] = take(off, (size_t)4 * o->Hn);
+    }
+    o->total = off;
+    return PCM_OK;
+}
+
+static const size_t GEMM_SCRATCH_FLOATS = 26u * 1024u * 1024u;
+
+int pcm_sg_scratch(const SGLayout &lay, SGScratch *o) {
+    memset(o, 0, sizeof(*o));
+    size_t off = 0;
+    o->off_dh = take(off, (size_t)lay.L * lay.B * lay.Hp);
+    o->off_dS = take(off, (size_t)2 * lay.B * (lay.use_stack ? lay.DW : 1));
+    o->off_dtop = take(off, (size_t)lay.B * (lay.use_stack ? lay.Wp : 1));
+    o->off_onehot = take(off, (size_t)lay.T * lay.B * lay.V);
+    o->off_dtokg = take(off, (size_t)lay.V * 3 * lay.H);
+    o->off_tmp = take(off, (size_t)lay.B * lay.Hp);
+    o->off_gemm = take(off, GEMM_SCRATCH_FLOATS);
+    o->gemm_bytes = GEMM_SCRATCH_FLOATS * sizeof(float);
+    o->total = off;
+    return PCM_OK;
+}
+
+// One StackGRU step on explicit state buffers (shared by forward / generate).
+struct StepBufs {
+    const float *h_prev[PCM_MAX_LAYERS];
+    float *h_new[PCM_MAX_LAYERS];
+    float *gates[PCM_MAX_LAYERS];
+    float *xdrop[PCM_MAX_LAYERS];  // dropped input OF layer l (l >= 1)
+    const float *S_prev;
+    float *S_new;
+    float *av;
+    float *xtop;
+    const int64_t *tok;
+};
+
+static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
+                        const float *sv_tokg, float *const *wpack,
+                        float *const *bpack, const StepBufs &sb,
+                        const int32_t *lengths, int t, float drop_p,
+                        uint64_t seed, int32_t *status, hipStream_t st) {
+    if (lay.use_stack) {
+        StackFwdArgs s;
+        s.htop = sb.h_prev[lay.L - 1];
+        s.S_prev = sb.S_prev; s.S_new = sb.S_new;
+        s.ctrl_w = w->ctrl_w; s.ctrl_b = w->ctrl_b;
+        s.push_w = w->push_w; s.push_b = w->push_b;
+        s.av = sb.av; s.xtop = sb.xtop; s.lengths = lengths;
+        s.B = lay.B; s.H = lay.H; s.Hp = lay.Hp; s.D = lay.D; s.W = lay.W;
+        s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
+        int rc = pcm_launch_stack_fwd(s, st);
+        if (rc) return rc;
+    }
+    for (int l = 0; l < lay.L; ++l) {
+        CellFwdArgs c;
+        c.xin = l == 0 ? sb.xtop : (lay.dropout ? sb.xdrop[l] : sb.h_new[l - 1]);
+        c.hprev = sb.h_prev[l];
+        c.wpack = wpack[l]; c.bpack = bpack[l];
+        c.tokg = l == 0 ? sv_tokg : nullptr;
+        c.tok = l == 0 ? sb.tok : nullptr;
+        c.hnew = sb.h_new[l];
+        c.gates = sb.gates[l];
+        c.xdrop = (lay.dropout && l + 1 < lay.L) ? sb.xdrop[l + 1] : nullptr;
+        c.lengths = lengths; c.status = status;
+        c.ldx = l == 0 ? lay.Wp : lay.Hp;
+        c.nx_chunks = lay.Kxp[l] / 64; c.nh_chunks = lay.Hp / 64;
+        c.Kp = lay.Kp[l];
+        c.B = lay.B; c.H = lay.H; c.Hn = lay.Hn; c.Hp = lay.Hp; c.V = lay.V;
+        c.t = t; c.next_layer = l + 1;
+        c.drop_p = drop_p; c.inv_keep = drop_p < 1.f ? 1.f / (1.f - drop_p) : 0.f;
+        c.seed = seed;
+        int rc = pcm_launch_cell_fwd(c, st);
+        if (rc) return rc;
+    }
+    return PCM_OK;
+}
+
+// pack weights + token gate table into the workspace
+static int enqueue_prepare(const SGLayout &lay, const pcm_stackgru_params *w,
+                           float *sv, hipStream_t st) {
+    const int ld0 = lay.E + lay.W;
+    for (int l = 0; l < lay.L; ++l) {
+        PackArgs p;
+        p.w_ih = w->w_ih[l]; p.w_hh = w->w_hh[l];
+        p.b_ih = w->b_ih[l]; p.b_hh = w->b_hh[l];
+        p.wpack = sv + lay.off_wpack[l]; p.bpack = sv + lay.off_bpack[l];
+        p.H = lay.H; p.Hn = lay.Hn; p.Hp = lay.Hp;
+        p.Kx = lay.Kx[l]; p.Kxp = lay.Kxp[l]; p.Kp = lay.Kp[l];
+        p.ld_ih = l == 0 ? ld0 : lay.H;
+        p.x_off = l == 0 ? lay.E : 0;
+        p.fold_bih = l == 0 ? 1 : 0;
+        pcm_launch_pack(p, st);
+    }
+    // tokg[v][g*Hn + j] = sum_e emb[v][e] * w_ih0[g*H + j][e] + b_ih0[g*H + j]
+    GemmBatch gb;
+    gb.count = 3;
+    for (int g = 0; g < 3; ++g) {
+        GemmProb p = pcm_gemm_prob(
+            w->emb, lay.E, 1, w->w_ih[0] + (long long)g * lay.H * ld0, 1, ld0,
+            sv + lay.off_tokg + (size_t)g * lay.Hn, 3LL * lay.Hn, lay.V, lay.H,
+            lay.E);
+        p.bias = w->b_ih[0] + (long long)g * lay.H;
+        gb.p[g] = p;
+    }
+    return pcm_gemm_launch(gb, nullptr, 0, st);
+}
+
+static int check_params(const SGLayout &lay, const pcm_stackgru_params *w,
+                        const char *who) {
+    PCM_REQUIRE(w, PCM_EINVAL, "%s: params is null", who);
+    PCM_REQUIRE(w->emb, PCM_EINVAL, "%s: embedding is null", who);
+    if (lay.use_stack)
+        PCM_REQUIRE(w->ctrl_w && w->ctrl_b && w->push_w && w->push_b,
+                    PCM_EINVAL, "%s: stack layer weights are null", who);
+    for (int l = 0; l < lay.L; ++l)
+        PCM_REQUIRE(w->w_ih[l] && w->w_hh[l] && w->b_ih[l] && w->b_hh[l],
+                    PCM_EINVAL, "%s: GRU layer %d weights are null", who, l);
+    return PCM_OK;
+}
+
+extern "C" {
+
+int pcm_version(void) { return 1; }
+
+const char *pcm_last_error(void) { return g_err; }
+
+int pcm_device_check(void) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    PCM_REQUIRE(e == hipSuccess, PCM_EDEVICE, "no HIP device: %s",
+                hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    PCM_REQUIRE(e == hipSuccess, PCM_EDEVICE, "device properties: %s",
+                hipGetErrorString(e));
+    PCM_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, PCM_EDEVICE,
+                "device %d is %s; this library is built for gfx950 only", dev,
+                prop.gcnArchName);
+    return PCM_OK;
+}
+
+size_t pcm_stackgru_saved_bytes(const pcm_dims *dims, int32_t steps,
+                                int32_t training) {
+    SGLayout lay;
+    if (pcm_sg_layout(dims, steps, training, 1, &lay)) return 0;
+    return lay.total * sizeof(float);
+}
+
+int pcm_stackgru_out_view(const pcm_dims *dims, int32_t steps, int32_t training,
+                          size_t *offset_floats, size_t *row_stride_floats) {
+    SGLayout lay;
+    int rc = pcm_sg_layout(dims, steps, training, 1, &lay);
+    if (rc) return rc;
+    PCM_REQUIRE(offset_floats && row_stride_floats, PCM_EINVAL,
+                "out_view: null output");
+    *offset_floats = lay.off_hs[lay.L - 1] + lay.hs_step();
+    *row_stride_floats = lay.Hp;
+    return PCM_OK;
+}
+
+size_t pcm_stackgru_scratch_bytes(const pcm_dims *dims, int32_t steps) {
+    SGLayout lay;
+    if (pcm_sg_layout(dims, steps, 1, 1, &lay)) return 0;
+    SGScratch sc;
+    pcm_sg_scratch(lay, &sc);
+    return sc.total * sizeof(float);
+}
+
+int pcm_stackgru_forward(const pcm_dims *dims,
+                         const pcm_stackgru_params *weights,
+                         const int64_t *tokens, int32_t steps,
+                         const int32_t *lengths, const float *h0,
+                         int64_t h0_layer_stride, const float *stack0,
+                         float dropout_p, uint64_t seed, int32_t training,
+                         void *saved, size_t saved_bytes, float *h_final,
+                         float *stack_final, int32_t *status, void *stream) {
+    SGLayout lay;
+    // the layout always reserves the dropout slots so that saved_bytes() does
+    // not depend on dropout_p; they are only written when dropout is active
+    int rc = pcm_sg_layout(dims, steps, training, 1, &lay);
+    if (rc) return rc;
+    rc = check_params(lay, weights, "stackgru_forward");
+    if (rc) return rc;
+    PCM_REQUIRE(tokens && saved, PCM_EINVAL, "stackgru_forward: null pointer");
+    PCM_REQUIRE(saved_bytes >= lay.total * sizeof(float), PCM_ENOMEM,
+                "stackgru_forward: saved workspace %zu < %zu bytes", saved_bytes,
+                lay.total * sizeof(float));
+    PCM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, PCM_EINVAL,
+                "stackgru_forward: dropout %f outside [0,1)", dropout_p);
+    PCM_REQUIRE(((uintptr_t)saved & 15) == 0, PCM_EINVAL,
+                "stackgru_forward: saved workspace must be 16-byte aligned");
+    const bool drop = training && dropout_p > 0.f && lay.L > 1;
+    lay.dropout = drop ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    float *sv = (float *)saved;
+
+    if (lay.Hp != lay.H) {
+        // zero the padding columns of every hidden-state slot once
+        for (int l = 0; l < lay.L; ++l)
+            pcm_launch_fill(sv + lay.off_hs[l], 0.f,
+                            (long long)(steps + 1) * lay.hs_step(), st);
+        if (drop)
+            for (int l = 1; l < lay.L; ++l)
+                pcm_launch_fill(sv + lay.off_xdrop[l], 0.f,
+                                (long long)steps * lay.hs_step(), st);
+    }
+    rc = enqueue_prepare(lay, weights, sv, st);
+    if (rc) return rc;
+    pcm_launch_init_state(lay, sv, h0, h0_layer_stride, stack0, st);
+
+    float *wpack[PCM_MAX_LAYERS], *bpack[PCM_MAX_LAYERS];
+    for (int l = 0; l < lay.L; ++l) {
+        wpack[l] = sv + lay.off_wpack[l];
+        bpack[l] = sv + lay.off_bpack[l];
+    }
+    for (int t = 0; t < steps; ++t) {
+        StepBufs sb;
+        memset(&sb, 0, sizeof(sb));
+        for (int l = 0; l < lay.L; ++l) {
+            sb.h_prev[l] = sv + lay.off_hs[l] + (size_t)t * lay.hs_step();
+            sb.h_new[l] = sv + lay.off_hs[l] + (size_t)(t + 1) * lay.hs_step();
+            sb.gates[l] = training ? sv + lay.off_gates[l] +
+                                         (size_t)t * lay.B * 4 * lay.H
+                                   : nullptr;
+            sb.xdrop[l] = (drop && l >= 1)
+                              ? sv + lay.off_xdrop[l] + (size_t)t * lay.hs_step()
+                              : nullptr;
+        }
+        if (lay.use_stack) {
+            sb.S_prev = sv + lay.s_index(t);
+            sb.S_new = sv + lay.s_index(t + 1);
+            sb.av = sv + lay.av_index(t);
+            sb.xtop = sv + lay.xtop_index(t);
+        }
+        sb.tok = tokens + (size_t)t * lay.B;
+        rc = enqueue_step(lay, weights, sv + lay.off_tokg, wpack, bpack, sb,
+                          lengths, t, dropout_p, seed, status, st);
+        if (rc) return rc;
+    }
+    if (h_final)
+        for (int l = 0; l < lay.L; ++l)
+            pcm_launch_copy_rows(
+                sv + lay.off_hs[l] + (size_t)steps * lay.hs_step(), lay.Hp,
+                h_final + (size_t)l * lay.B * lay.H, lay.H, lay.B, lay.H, st);
+    if (stack_final && lay.use_stack)
+        pcm_launch_copy_rows(sv + lay.s_index(steps), lay.DW, stack_final,
+                             lay.DW, lay.B, lay.DW, st);
+    return pcm_check_launch("stackgru_forward");
+}
+
+int pcm_stackgru_backward(const pcm_dims *dims,
+                          const pcm_stackgru_params *weights,
+                          const int64_t *tokens, int32_t steps,
+                          const int32_t *lengths, float dropout_p,
+                          uint64_t seed, void *saved, size_t saved_bytes,
+                          const float *d_out, int64_t d_out_row_stride,
+                          const float *d_h_final, const float *d_stack_final,
+                          float *d_h0, float *d_stack0,
+                          const pcm_stackgru_params *grads, int32_t accumulate,
+                          void *scratch, size_t scratch_bytes, void *stream) {
+    SGLayout lay;
+    int rc = pcm_sg_layout(dims, steps, 1, 1, &lay);
+    if (rc) return rc;
+    rc = check_params(lay, weights, "stackgru_backward");
+    if (rc) return rc;
+    PCM_REQUIRE(tokens && saved && scratch && grads, PCM_EINVAL,
+                "stackgru_backward: null pointer");
+    PCM_REQUIRE(saved_bytes >= lay.total * sizeof(float), PCM_ENOMEM,
+                "stackgru_backward: saved workspace too small");
+    SGScratch sc;
+    pcm_sg_scratch(lay, &sc);
+    PCM_REQUIRE(scratch_bytes >= sc.total * sizeof(float), PCM_ENOMEM,
+                "stackgru_backward: scratch %zu < %zu bytes", scratch_bytes,
+                sc.total * sizeof(float));
+    const bool drop = dropout_p > 0.f && lay.L > 1;
+    lay.dropout = drop ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    float *sv = (float *)saved;
+    float *scf = (float *)scratch;
+    const int B = lay.B, H = lay.H, Hp = lay.Hp, L = lay.L, T = steps;
+    const int ld0 = lay.E + lay.W;
+    void *gs = scf + sc.off_gemm;
+    const size_t gsb = sc.gemm_bytes;
+
+    // running gradients
+    float *dh = scf + sc.off_dh;  // [L][B][Hp]
+    pcm_launch_fill(dh, 0.f, (long long)L * B * Hp, st);
+    if (d_h_final)
+        for (int l = 0; l < L; ++l)
+            pcm_launch_copy_rows(d_h_final + (size_t)l * B * H, H,
+                                 dh + (size_t)l * B * Hp, Hp, B, H, st);
+    float *dS[2] = {scf + sc.off_dS, scf + sc.off_dS + (size_t)B * lay.DW};
+    int cur = 0;
+    if (lay.use_stack) {
+        if (d_stack_final)
+            pcm_launch_copy_rows(d_stack_final, lay.DW, dS[0], lay.DW, B, lay.DW,
+                                 st);
+        else
+            pcm_launch_fill(dS[0], 0.f, (long long)B * lay.DW, st);
+    }
+    float *dtop = scf + sc.off_dtop;
+    float *tmp = scf + sc.off_tmp;
+
+    for (int t = T - 1; t >= 0; --t) {
+        for (int l = L - 1; l >= 0; --l) {
+            float *gates = sv + lay.off_gates[l] + (size_t)t * B * 4 * H;
+            float *dhl = dh + (size_t)l * B * Hp;
+            GateBwdArgs g;
+            g.dh = dhl;
+            g.dout = (l == L - 1 && d_out)
+                         ? d_out + (size_t)t * B * d_out_row_stride
+                         : nullptr;
+            g.ld_dout = d_out_row_stride;
+            g.gates = gates;
+            g.hprev = sv + lay.off_hs[l] + (size_t)t * lay.hs_step();
+            g.lengths = lengths; g.B = B; g.H = H; g.Hp = Hp; g.t = t;
+            pcm_launch_gate_bwd(g, st);
+
+            // dh[l] += dGh . W_hh  (dGh = cols [0,2H) and [3H,4H) of gates)
+            GemmBatch gb;
+            gb.count = 0;
+            const bool seg_ok = ((2 * H) % 16) == 0;
+            GemmProb p1 = pcm_gemm_prob(gates, 4LL * H, 1, weights->w_hh[l], H,
+                                        1, dhl, Hp, B, H, seg_ok ? 3 * H : 2 * H);
+            p1.accumulate = 1;
+            if (seg_ok) {
+                p1.K1 = 2 * H;
+                p1.A2 = gates + 3 * H;
+                p1.B2 = weights->w_hh[l] + (size_t)2 * H * H;
+            }
+            gb.p[gb.count++] = p1;
+            // input-side product
+            const bool use_tmp = (l > 0 && drop);
+            if (l > 0) {
+                GemmProb p2 = pcm_gemm_prob(
+                    gates, 4LL * H, 1, weights->w_ih[l], H, 1,
+                    use_tmp ? tmp : dh + (size_t)(l - 1) * B * Hp, Hp, B, H,
+                    3 * H);
+                p2.accumulate = use_tmp ? 0 : 1;
+                gb.p[gb.count++] = p2;
+            } else if (lay.use_stack) {
+                GemmProb p2 = pcm_gemm_prob(gates, 4LL * H, 1,
+                                            weights->w_ih[0] + lay.E, ld0, 1,
+                                            dtop, lay.Wp, B, lay.W, 3 * H);
+                gb.p[gb.count++] = p2;
+            }
+            rc = pcm_gemm_launch(gb, gs, gsb, st);
+            if (rc) return rc;
+            if (!seg_ok) {
+                GemmBatch g2;
+                g2.count = 1;
+                GemmProb p3 = pcm_gemm_prob(gates + 3 * H, 4LL * H, 1,
+                                            weights->w_hh[l] + (size_t)2 * H * H,
+                                            H, 1, dhl, Hp, B, H, H);
+                p3.accumulate = 1;
+                g2.p[0] = p3;
+                rc = pcm_gemm_launch(g2, gs, gsb, st);
+                if (rc) return rc;
+            }
+            if (use_tmp)
+                pcm_launch_dropout_add(dh + (size_t)(l - 1) * B * Hp, Hp, tmp, Hp,
+                                       B, H, seed, l, t, dropout_p, st);
+        }
+        if (lay.use_stack) {
+            StackBwdArgs s;
+            s.dS_next = dS[cur]; s.dS_prev = dS[cur ^ 1];
+            s.dtop = dtop;
+            s.S_prev = sv + lay.s_index(t);
+            s.av = sv + lay.av_index(t);
+            s.ctrl_w = weights->ctrl_w; s.push_w = weights->push_w;
+            s.dh_top = dh + (size_t)(L - 1) * B * Hp;
+            s.lengths = lengths;
+            s.B = B; s.H = H; s.Hp = Hp; s.D = lay.D; s.W = lay.W;
+            s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
+            pcm_launch_stack_bwd(s, st);
+            cur ^= 1;
+        }
+    }
+    if (d_h0)
+        for (int l = 0; l < L; ++l)
+            pcm_launch_copy_rows(dh + (size_t)l * B * Hp, Hp,
+                                 d_h0 + (size_t)l * B * H, H, B, H, st);
+    if (d_stack0 && lay.use_stack)
+        pcm_launch_copy_rows(dS[cur], lay.DW, d_stack0, lay.DW, B, lay.DW, st);
+
+    // ---- time-parallel parameter gradients (K = T*B rows) -------------------------
+    const int R = T * B;
+    const int acc = accumulate ? 1 : 0;
+    {
+        GemmBatch gb;
+        gb.count = 0;
+        auto flush = [&]() -> int {
+            if (gb.count == 0) return PCM_OK;
+            int r = pcm_gemm_launch(gb, gs, gsb, st);
+            gb.count = 0;
+            return r;
+        };
+        auto push = [&](GemmProb p) -> int {
+            p.accumulate = acc;
+            gb.p[gb.count++] = p;
+            if (gb.count == PCM_GEMM_MAX_PROBS) return flush();
+            return PCM_OK;
+        };
+        // large, square-ish products first (share the 128x128 configuration)
+        for (int l = 0; l < L; ++l) {
+            const float *G = sv + lay.off_gates[l];
+            const float *hprev = sv + lay.off_hs[l];  // rows t*B+b, t < T
+            if (grads->w_hh[l]) {
+                rc = push(pcm_gemm_prob(G, 1, 4LL * H, hprev, Hp, 1,
+                                        grads->w_hh[l], H, 2 * H, H, R));
+                if (rc) return rc;
+                rc = push(pcm_gemm_prob(G + 3 * H, 1, 4LL * H, hprev, Hp, 1,
+                                        grads->w_hh[l] + (size_t)2 * H * H, H, H,
+                                        H, R));
+                if (rc) return rc;
+            }
+            if (l > 0 && grads->w_ih[l]) {
+                const float *x = drop ? sv + lay.off_xdrop[l]
+                                      : sv + lay.off_hs[l - 1] + lay.hs_step();
+                rc = push(pcm_gemm_prob(G, 1, 4LL * H, x, Hp, 1, grads->w_ih[l],
+                                        H, 3 * H, H, R));
+                if (rc) return rc;
+            }
+        }
+        rc = flush();
+        if (rc) return rc;
+        // skinny products
+        const float *G0 = sv + lay.off_gates[0];
+        if (grads->w_ih[0] && lay.use_stack) {
+            rc = push(pcm_gemm_prob(G0, 1, 4LL * H, sv + lay.off_xtop, lay.Wp, 1,
+                                    grads->w_ih[0] + lay.E, ld0, 3 * H, lay.W,
+                                    R));
+            if (rc) return rc;
+        }
+        if (lay.use_stack) {
+            const float *dav = sv + lay.off_av;
+            const float *htop = sv + lay.off_hs[L - 1];
+            if (grads->ctrl_w) {
+                rc = push(pcm_gemm_prob(dav, 1, lay.AVW, htop, Hp, 1,
+                                        grads->ctrl_w, H, 3, H, R));
+                if (rc) return rc;
+            }
+            if (grads->push_w) {
+                rc = push(pcm_gemm_prob(dav + 3, 1, lay.AVW, htop, Hp, 1,
+                                        grads->push_w, H, lay.W, H, R));
+                if (rc) return rc;
+            }
+        }
+        rc = flush();
+        if (rc) return rc;
+        // token path: dtokg = onehot^T . dGi0, then dW_ih0[:, :E] and dEmb
+        if (grads->w_ih[0] || grads->emb) {
+            float *onehot = scf + sc.off_onehot;
+            float *dtokg = scf + sc.off_dtokg;
+            pcm_launch_onehot(tokens, (long long)R, lay.V, onehot, st);
+            GemmBatch g1;
+            g1.count = 1;
+            g1.p[0] = pcm_gemm_prob(onehot, 1, lay.V, G0, 4LL * H, 1, dtokg,
+                                    3LL * H, lay.V, 3 * H, R);
+            rc = pcm_gemm_launch(g1, gs, gsb, st);
+            if (rc) return rc;
+            GemmBatch g2;
+            g2.count = 0;
+            if (grads->w_ih[0]) {
+                GemmProb p = pcm_gemm_prob(dtokg, 1, 3LL * H, weights->emb, lay.E,
+                                           1, grads->w_ih[0], ld0, 3 * H, lay.E,
+                                           lay.V);
+                p.accumulate = acc;
+                g2.p[g2.count++] = p;
+            }
+            if (grads->emb) {
+                GemmProb p = pcm_gemm_prob(dtokg, 3LL * H, 1, weights->w_ih[0],
+                                           ld0, 1, grads->emb, lay.E, lay.V,
+                                           lay.E, 3 * H);
+                p.accumulate = acc;
+                g2.p[g2.count++] = p;
+            }
+            rc = pcm_gemm_launch(g2, gs, gsb, st);
+            if (rc) return rc;
+        }
+        // biases: column sums of the gate gradients
+        for (int l = 0; l < L; ++l) {
+            const float *G = sv + lay.off_gates[l];
+            if (grads->b_ih[l]) {
+                rc = pcm_colsum_launch(G, 4LL * H, R, 3 * H, grads->b_ih[l],
+                                       nullptr, acc, gs, gsb, st);
+                if (rc) return rc;
+            }
+            if (grads->b_hh[l]) {
+                rc = pcm_colsum_launch(G, 4LL * H, R, 2 * H, grads->b_hh[l],
+                                       nullptr, acc, gs, gsb, st);
+                if (rc) return rc;
+                rc = pcm_colsum_launch(G + 3 * H, 4LL * H, R, H,
+                                       grads->b_hh[l] + 2 * H, nullptr, acc, gs,
+                                       gsb, st);
+                if (rc) return rc;
+            }
+        }
+        if (lay.use_stack) {
+            const float *dav = sv + lay.off_av;
+            if (grads->ctrl_b) {
+                rc = pcm_colsum_launch(dav, lay.AVW, R, 3, grads->ctrl_b,
+                                       nullptr, acc, gs, gsb, st);
+                if (rc) return rc;
+            }
+            if (grads->push_b) {
+                rc = pcm_colsum_launch(dav + 3, lay.AVW, R, lay.W, grads->push_b,
+                                       nullptr, acc, gs, gsb, st);
+                if (rc) return rc;
+            }
+        }
+    }
+    return pcm_check_launch("stackgru_backward");
+}
+
+// ---- dense layers -------------------------------------------------------------------
+int pcm_linear_forward(const float *x, int64_t ldx, const float *w,
+                       const float *b, float *y, int64_t ldy, int32_t m,
+                       int32_t n, int32_t k, void *stream) {
+    PCM_REQUIRE(x && w && y && m > 0 && n > 0 && k > 0, PCM_EINVAL,
+                "linear_forward: bad args");
+    GemmBatch gb;
+    gb.count = 1;
+    gb.p[0] = pcm_gemm_prob(x, ldx, 1, w, 1, k, y, ldy, m, n, k);
+    gb.p[0].bias = b;
+    return pcm_gemm_launch(gb, nullptr, 0, (hipStream_t)stream);
+}
+
+size_t pcm_linear_scratch_bytes(int32_t m, int32_t n, int32_t k) {
+    (void)k;
+    size_t a = GEMM_SCRATCH_FLOATS * sizeof(float);
+    size_t b = pcm_colsum_scratch_bytes(m, n);
+    return a > b ? a : b;
+}
+
+int pcm_linear_backward(const float *x, int64_t ldx, const float *w,
+                        const float *dy, const float *dy_scale, int64_t lddy,
+                        float *dx, int64_t lddx,
+                        float *dw, float *db, int32_t m, int32_t n, int32_t k,
+                        int32_t accumulate, void *scratch,
+                        size_t scratch_bytes, void *stream) {
+    PCM_REQUIRE(dy && m > 0 && n > 0 && k > 0, PCM_EINVAL,
+                "linear_backward: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (dx) {
+        PCM_REQUIRE(w, PCM_EINVAL, "linear_backward: dx needs w");
+        GemmBatch gb;
+        gb.count = 1;
+        gb.p[0] = pcm_gemm_prob(dy, lddy, 1, w, k, 1, dx, lddx, m, k, n);
+        gb.p[0].alpha_ptr = dy_scale;
+        rc = pcm_gemm_launch(gb, scratch, scratch_bytes, st);
+        if (rc) return rc;
+    }
+    if (dw) {
+        PCM_REQUIRE(x, PCM_EINVAL, "linear_backward: dw needs x");
+        GemmBatch gb;
+        gb.count = 1;
+        gb.p[0] = pcm_gemm_prob(dy, 1, lddy, x, ldx, 1, dw, k, n, k, m);
+        gb.p[0].accumulate = accumulate ? 1 : 0;
+        gb.p[0].alpha_ptr = dy_scale;
+        rc = pcm_gemm_launch(gb, scratch, scratch_bytes, st);
+        if (rc) return rc;
+    }
+    if (db) {
+        rc = pcm_colsum_launch(dy, lddy, m, n, db, dy_scale, accumulate ? 1 : 0,
+                               scratch, scratch_bytes, st);
+        if (rc) return rc;
+    }
+    return PCM_OK;
+}
+
+// ---- generation ----------------------------------------------------------------------
+struct GenLayout {
+    SGLayout lay;
+    size_t off_h[2][PCM_MAX_LAYERS];
+    size_t off_S[2];
+    size_t off_av, off_xtop, off_tokg, off_logits, off_tok;
+    size_t off_wpack[PCM_MAX_LAYERS], off_bpack[PCM_MAX_LAYERS];
+    size_t total;
+};
+
+static int gen_layout(const pcm_dims *dims, GenLayout *g) {
+    int rc = pcm_sg_layout(dims, 1, 0, 0, &g->lay);
+    if (rc) return rc;
+    const SGLayout &lay = g->lay;
+    size_t off = 0;
+    for (int s = 0; s < 2; ++s)
+        for (int l = 0; l < lay.L; ++l)
+            g->off_h[s][l] = take(off, (size_t)lay.B * lay.Hp);
+    for (int s = 0; s < 2; ++s)
+        g->off_S[s] = take(off, (size_t)lay.B * (lay.use_stack ? lay.DW : 1));
+    g->off_av = take(off, (size_t)lay.B * (lay.use_stack ? lay.AVW : 1));
+    g->off_xtop = take(off, (size_t)lay.B * (lay.use_stack ? lay.Wp : 1));
+    g->off_tokg = take(off, (size_t)lay.V * 3 * lay.Hn);
+    g->off_logits = take(off, (size_t)lay.B * lay.V);
+    g->off_tok = take(off, (size_t)lay.B * 2);  // int64[B]
+    for (int l = 0; l < lay.L; ++l) {
+        g->off_wpack[l] = take(off, (size_t)3 * lay.Hn * lay.Kp[l]);
+        g->off_bpack[l] = take(off, (size_t)4 * lay.Hn);
+    }
+    g->total = off;
+    return PCM_OK;
+}
+
+size_t pcm_generate_workspace_bytes(const pcm_dims *dims) {
+    GenLayout g;
+    if (gen_layout(dims, &g)) return 0;
+    return g.total * sizeof(float);
+}
+
+int pcm_stackgru_generate(const pcm_dims *dims,
+                          const pcm_stackgru_params *weights,
+                          const float *out_w, const float *out_b,
+                          const float *h0, int64_t h0_layer_stride,
+                          const int64_t *prime, int32_t prime_len,
+                          int32_t generate_len, int32_t search,
+                          float temperature, uint64_t seed,
+                          int64_t *tokens_out, float *logits_out,
+                          void *workspace, size_t workspace_bytes,
+                          int32_t *status, void *stream) {
+    GenLayout g;
+    int rc = gen_layout(dims, &g);
+    if (rc) return rc;
+    SGLayout &lay = g.lay;
+    rc = check_params(lay, weights, "stackgru_generate");
+    if (rc) return rc;
+    PCM_REQUIRE(out_w && prime && tokens_out && workspace, PCM_EINVAL,
+                "stackgru_generate: null pointer");
+    PCM_REQUIRE(prime_len >= 1 && generate_len >= 0, PCM_EINVAL,
+                "stackgru_generate: prime_len=%d generate_len=%d", prime_len,
+                generate_len);
+    PCM_REQUIRE(search == PCM_SEARCH_GREEDY || search == PCM_SEARCH_SAMPLING,
+                PCM_EINVAL, "stackgru_generate: unknown search %d", search);
+    PCM_REQUIRE(search != PCM_SEARCH_SAMPLING || temperature > 0.f, PCM_EINVAL,
+                "stackgru_generate: temperature must be positive");
+    PCM_REQUIRE(workspace_bytes >= g.total * sizeof(float), PCM_ENOMEM,
+                "stackgru_generate: workspace %zu < %zu bytes", workspace_bytes,
+                g.total * sizeof(float));
+    hipStream_t st = (hipStream_t)stream;
+    float *ws = (float *)workspace;
+    const int B = lay.B, H = lay.H, Hp = lay.Hp, L = lay.L, V = lay.V;
+    const long long out_stride = (long long)prime_len + generate_len;
+
+    // weights, token table: reuse the forward preparation on a layout whose
+    // offsets point into this workspace
+    SGLayout prep = lay;
+    prep.off_tokg = g.off_tokg;
+    for (int l = 0; l < L; ++l) {
+        prep.off_wpack[l] = g.off_wpack[l];
+        prep.off_bpack[l] = g.off_bpack[l];
+    }
+    rc = enqueue_prepare(prep, weights, ws, st);
+    if (rc) return rc;
+    float *wpack[PCM_MAX_LAYERS], *bpack[PCM_MAX_LAYERS];
+    for (int l = 0; l < L; ++l) {
+        wpack[l] = ws + g.off_wpack[l];
+        bpack[l] = ws + g.off_bpack[l];
+    }
+    // initial state
+    if (Hp != H)
+        for (int s = 0; s < 2; ++s)
+            for (int l = 0; l < L; ++l)
+                pcm_launch_fill(ws + g.off_h[s][l], 0.f, (long long)B * Hp, st);
+    for (int l = 0; l < L; ++l) {
+        if (h0)
+            pcm_launch_copy_rows(h0 + (long long)l * h0_layer_stride, H,
+                                 ws + g.off_h[0][l], Hp, B, H, st);
+        else
+            pcm_launch_fill(ws + g.off_h[0][l], 0.f, (long long)B * Hp, st);
+    }
+    if (lay.use_stack)
+        pcm_launch_fill(ws + g.off_S[0], 0.f, (long long)B * lay.DW, st);
+    int64_t *cur_tok = (int64_t *)(ws + g.off_tok);
+    for (int p = 0; p < prime_len; ++p)
+        pcm_launch_broadcast_token(prime + p, B, nullptr, tokens_out, out_stride,
+                                   p, st);
+
+    const int total_steps = (prime_len - 1) + generate_len;
+    int slot = 0;
+    for (int s = 0; s < total_steps; ++s) {
+        const bool priming = s < prime_len - 1;
+        if (s < prime_len)
+            pcm_launch_broadcast_token(prime + s, B, cur_tok, nullptr, 0, 0, st);
+        StepBufs sb;
+        memset(&sb, 0, sizeof(sb));
+        for (int l = 0; l < L; ++l) {
+            sb.h_prev[l] = ws + g.off_h[slot][l];
+            sb.h_new[l] = ws + g.off_h[slot ^ 1][l];
+        }
+        if (lay.use_stack) {
+            sb.S_prev = ws + g.off_S[slot];
+            sb.S_new = ws + g.off_S[slot ^ 1];
+            sb.av = ws + g.off_av;
+            sb.xtop = ws + g.off_xtop;
+        }
+        sb.tok = cur_tok;
+        rc = enqueue_step(lay, weights, ws + g.off_tokg, wpack, bpack, sb,
+                          nullptr, s, 0.f, 0, status, st);
+        if (rc) return rc;
+        slot ^= 1;
+        if (!priming) {
+            const int gi = s - (prime_len - 1);
+            float *logits = logits_out ? logits_out + (size_t)gi * B * V
+                                       : ws + g.off_logits;
+            rc = pcm_linear_forward(ws + g.off_h[slot][L - 1], Hp, out_w, out_b,
+                                    logits, V, B, V, H, st);
+            if (rc) return rc;
+            pcm_launch_choose(logits, B, V, search, temperature, seed, gi,
+                              cur_tok, tokens_out, out_stride, prime_len + gi,
+                              st);
+        }
+    }
+    return pcm_check_launch("stackgru_generate");
+}
+
+}  // extern "C"

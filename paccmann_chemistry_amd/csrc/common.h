@@ -1,0 +1,103 @@
+// Shared declarations of libpaccmann_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/paccmann_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PCM_WAVE 64
+
+// ---- error plumbing -----------------------------------------------------------
+void pcm_set_error(const char *fmt, ...);
+int pcm_check_launch(const char *what);
+
+#define PCM_REQUIRE(cond, code, ...)   \
+    do {                               \
+        if (!(cond)) {                 \
+            pcm_set_error(__VA_ARGS__); \
+            return (code);             \
+        }                              \
+    } while (0)
+
+static inline int64_t pcm_round_up(int64_t v, int64_t m) {
+    return (v + m - 1) / m * m;
+}
+
+// ---- generic grouped fp32 MFMA GEMM (gemm.hip) ------------------------------
+// C[m][n] (+)= alpha * sum_k A[m][k] * B[k][n] + bias[n]
+// A[m][k] at A + m*a_rs + k*a_cs; B[k][n] at B + k*b_rs + n*b_cs.
+// Optional second K segment: for k >= K1 the operands come from A2 / B2 at
+// index k-K1 (K1 must be a multiple of 16); K1 == 0 disables it.
+struct GemmProb {
+    const float *A;
+    const float *B;
+    const float *A2;
+    const float *B2;
+    float *C;
+    const float *bias;
+    const float *alpha_ptr;  // device scalar (nullable -> 1)
+    long long a_rs, a_cs, b_rs, b_cs, ldc;
+    int M, N, K, K1;
+    int accumulate;
+};
+
+#define PCM_GEMM_MAX_PROBS 8
+struct GemmBatch {
+    GemmProb p[PCM_GEMM_MAX_PROBS];
+    int count;
+};
+
+// Bytes of split-K slab scratch pcm_gemm_launch may need for this batch.
+size_t pcm_gemm_scratch_bytes(const GemmBatch &batch);
+// Launch a grouped GEMM.  scratch may be NULL (then no split-K is used).
+int pcm_gemm_launch(const GemmBatch &batch, void *scratch,
+                    size_t scratch_bytes, hipStream_t stream);
+
+static inline GemmProb pcm_gemm_prob(const float *A, long long a_rs,
+                                     long long a_cs, const float *B,
+                                     long long b_rs, long long b_cs, float *C,
+                                     long long ldc, int M, int N, int K) {
+    GemmProb p;
+    p.A = A; p.B = B; p.A2 = nullptr; p.B2 = nullptr; p.C = C;
+    p.bias = nullptr; p.alpha_ptr = nullptr;
+    p.a_rs = a_rs; p.a_cs = a_cs; p.b_rs = b_rs; p.b_cs = b_cs; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.K1 = 0; p.accumulate = 0;
+    return p;
+}
+
+// column sums: out[n] (+)= alpha * sum_m X[m*ldx + n]  (deterministic, 2 stage)
+size_t pcm_colsum_scratch_bytes(int M, int N);
+int pcm_colsum_launch(const float *X, long long ldx, int M, int N, float *out,
+                      const float *alpha_ptr, int accumulate, void *scratch,
+                      size_t scratch_bytes, hipStream_t stream);
+
+// ---- device helpers -------------------------------------------------------------
+__device__ __forceinline__ float pcm_sigmoid(float x) {
+    return 1.0f / (1.0f + expf(-x));
+}
+
+// Counter-based uniform in [0,1): splitmix64 finaliser of (seed, counter).
+__host__ __device__ __forceinline__ uint64_t pcm_mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ __forceinline__ float pcm_uniform(uint64_t seed,
+                                                      uint64_t counter) {
+    uint64_t h = pcm_mix64(seed ^ pcm_mix64(counter));
+    return (float)(h >> 40) * (1.0f / 16777216.0f);
+}
+// Inter-layer dropout multiplier for element (layer, t, b, j).
+__device__ __forceinline__ float pcm_dropout_scale(uint64_t seed, int layer,
+                                                   int t, int b, int j,
+                                                   float p, float inv_keep) {
+    uint64_t ctr = ((uint64_t)(uint32_t)layer << 56) ^
+                   ((uint64_t)(uint32_t)t << 40) ^
+                   ((uint64_t)(uint32_t)b << 16) ^ (uint64_t)(uint32_t)j;
+    return pcm_uniform(seed, ctr) < p ? 0.0f : inv_keep;
+}

@@ -1,0 +1,324 @@
+// Generic grouped fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, fmaf-chain
+// numerics) with arbitrary operand strides, an optional second K segment,
+// deterministic split-K (slabs + ordered reduce), bias / alpha epilogue.
+//
+// Used for every time-parallel product of the path: token gate table,
+// logits, mu/logvar, latent->hidden, all weight gradients (sum over T*B rows)
+// and, in the reverse recurrence, the per-step dgates.W products.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 16;
+
+struct SlabInfo {
+    long long off[PCM_GEMM_MAX_PROBS];  // float offset of each problem's slabs
+};
+
+// Work-group tile = (64*TM) x (64*TN); 4 waves as 2x2, each TM x TN MFMA tiles.
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch, int splits,
+                                                   float *slab,
+                                                   SlabInfo slabs) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int LDA = BM + 1, LDB = BN + 1;
+    constexpr int NA = 4 * TM, NB = 4 * TN;  // elements per thread per chunk
+    __shared__ float As[2][BK * LDA];
+    __shared__ float Bs[2][BK * LDB];
+
+    const int pz = blockIdx.z / splits;
+    const int sk = blockIdx.z - pz * splits;
+    const GemmProb &p = batch.p[pz];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (m0 >= p.M || n0 >= p.N) return;
+
+    const int nchunks = (p.K + BK - 1) / BK;
+    const int cps = (nchunks + splits - 1) / splits;
+    const int c0 = sk * cps;
+    const int c1 = min(nchunks, c0 + cps);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const bool a_mfast = (p.a_rs == 1 && p.a_cs != 1);
+    const bool b_nfast = (p.b_cs == 1);
+
+    float ra[NA], rb[NB];
+
+    auto load_chunk = [&](int c) {
+        const int kb = c * BK;
+        const bool seg2 = (p.K1 > 0 && kb >= p.K1);
+        const float *Ab = seg2 ? p.A2 : p.A;
+        const float *Bb = seg2 ? p.B2 : p.B;
+        const int kshift = seg2 ? p.K1 : 0;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + 256 * i;
+            int m, k;
+            if (a_mfast) { m = e % BM; k = e / BM; }
+            else { k = e % BK; m = e / BK; }
+            const int gm = m0 + m, gk = kb + k;
+            float v = 0.0f;
+            if (gm < p.M && gk < p.K)
+                v = Ab[(long long)gm * p.a_rs + (long long)(gk - kshift) * p.a_cs];
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = tid + 256 * i;
+            int n, k;
+            if (b_nfast) { n = e % BN; k = e / BN; }
+            else { k = e % BK; n = e / BK; }
+            const int gn = n0 + n, gk = kb + k;
+            float v = 0.0f;
+            if (gn < p.N && gk < p.K)
+                v = Bb[(long long)(gk - kshift) * p.b_rs + (long long)gn * p.b_cs];
+            rb[i] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int e = tid + 256 * i;
+            int m, k;
+            if (a_mfast) { m = e % BM; k = e / BM; }
+            else { k = e % BK; m = e / BK; }
+            As[buf][k * LDA + m] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = tid + 256 * i;
+            int n, k;
+            if (b_nfast) { n = e % BN; k = e / BN; }
+            else { k = e % BK; n = e / BK; }
+            Bs[buf][k * LDB + n] = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int lrow = lane & 31, lk = lane >> 5;
+    if (c0 < c1) load_chunk(c0);
+    int buf = 0;
+    for (int c = c0; c < c1; ++c) {
+        store_chunk(buf);
+        __syncthreads();
+        if (c + 1 < c1) load_chunk(c + 1);
+        const float *as = &As[buf][0];
+        const float *bs = &Bs[buf][0];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                a[i] = as[(kk + lk) * LDA + (wm * TM + i) * 32 + lrow];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = bs[(kk + lk) * LDB + (wn * TN + j) * 32 + lrow];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+
+    // epilogue: lane holds column (lane&31), rows (r&3)+8*(r>>2)+4*(lane>>5)
+    const float alpha = p.alpha_ptr ? *p.alpha_ptr : 1.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int gn = n0 + (wn * TN + j) * 32 + lrow;
+            if (gn >= p.N) continue;
+            const float bias = (p.bias && splits == 1) ? p.bias[gn] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) +
+                               4 * lk;
+                if (gm >= p.M) continue;
+                if (splits == 1) {
+                    float *c = p.C + (long long)gm * p.ldc + gn;
+                    float v = alpha * acc[i][j][r] + bias;
+                    if (p.accumulate) v += *c;
+                    *c = v;
+                } else {
+                    slab[slabs.off[pz] +
+                         ((long long)sk * p.M + gm) * p.N + gn] = acc[i][j][r];
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmBatch batch,
+                                                            int splits,
+                                                            const float *slab,
+                                                            SlabInfo slabs) {
+    const GemmProb &p = batch.p[blockIdx.y];
+    const long long total = (long long)p.M * p.N;
+    const float alpha = p.alpha_ptr ? *p.alpha_ptr : 1.0f;
+    const float *base = slab + slabs.off[blockIdx.y];
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+         e < total; e += (long long)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int k = 0; k < splits; ++k) s += base[(long long)k * total + e];
+        const int m = (int)(e / p.N), n = (int)(e - (long long)m * p.N);
+        float v = alpha * s + (p.bias ? p.bias[n] : 0.0f);
+        float *c = p.C + (long long)m * p.ldc + n;
+        if (p.accumulate) v += *c;
+        *c = v;
+    }
+}
+
+struct Plan {
+    int big;     // 1: 128x128 tiles, 0: 64x64
+    int splits;
+    int gx, gy;
+};
+
+Plan make_plan(const GemmBatch &batch, bool allow_split) {
+    Plan pl;
+    long long tiles64 = 0, tiles128 = 0;
+    int maxM = 0, maxN = 0, minK = 1 << 30;
+    for (int i = 0; i < batch.count; ++i) {
+        const GemmProb &p = batch.p[i];
+        tiles64 += (long long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+        tiles128 += (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+        maxM = std::max(maxM, p.M);
+        maxN = std::max(maxN, p.N);
+        minK = std::min(minK, p.K);
+    }
+    pl.big = tiles128 >= 128 ? 1 : 0;
+    const long long tiles = pl.big ? tiles128 : tiles64;
+    const int bm = pl.big ? 128 : 64;
+    pl.gx = (maxN + bm - 1) / bm;
+    pl.gy = (maxM + bm - 1) / bm;
+    int splits = 1;
+    if (allow_split && tiles < 512) {
+        const int chunks = (minK + BK - 1) / BK;
+        splits = (int)((768 + tiles - 1) / tiles);
+        splits = std::min(splits, chunks / 16);  // >= 256 k per split
+        splits = std::max(1, std::min(splits, 64));
+        // second K segment requires chunk-aligned splits only (always true)
+    }
+    pl.splits = splits;
+    return pl;
+}
+
+}  // namespace
+
+size_t pcm_gemm_scratch_bytes(const GemmBatch &batch) {
+    Plan pl = make_plan(batch, true);
+    if (pl.splits == 1) return 0;
+    size_t total = 0;
+    for (int i = 0; i < batch.count; ++i)
+        total += (size_t)pl.splits * batch.p[i].M * batch.p[i].N;
+    return total * sizeof(float);
+}
+
+int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
+                    hipStream_t stream) {
+    PCM_REQUIRE(batch.count >= 1 && batch.count <= PCM_GEMM_MAX_PROBS,
+                PCM_EINVAL, "gemm: bad problem count %d", batch.count);
+    for (int i = 0; i < batch.count; ++i) {
+        const GemmProb &p = batch.p[i];
+        PCM_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && p.A && p.B && p.C,
+                    PCM_EINVAL, "gemm: empty problem %d (%d,%d,%d)", i, p.M,
+                    p.N, p.K);
+        PCM_REQUIRE(p.K1 % BK == 0 && p.K1 >= 0 && p.K1 < p.K, PCM_EINVAL,
+                    "gemm: K1=%d must be a multiple of %d below K", p.K1, BK);
+        PCM_REQUIRE(p.K1 == 0 || (p.A2 && p.B2), PCM_EINVAL,
+                    "gemm: second K segment without operands");
+    }
+    Plan pl = make_plan(batch, scratch != nullptr);
+    SlabInfo slabs;
+    size_t need = 0;
+    for (int i = 0; i < PCM_GEMM_MAX_PROBS; ++i) slabs.off[i] = 0;
+    if (pl.splits > 1) {
+        for (int i = 0; i < batch.count; ++i) {
+            slabs.off[i] = (long long)need;
+            need += (size_t)pl.splits * batch.p[i].M * batch.p[i].N;
+        }
+        if (need * sizeof(float) > scratch_bytes) {
+            pl.splits = 1;  // fall back to a single pass, still correct
+        }
+    }
+    dim3 grid(pl.gx, pl.gy, batch.count * pl.splits);
+    float *slab = (float *)scratch;
+    if (pl.big)
+        hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), 0, stream,
+                           batch, pl.splits, slab, slabs);
+    else
+        hipLaunchKernelGGL((gemm_kernel<1, 1>), grid, dim3(256), 0, stream,
+                           batch, pl.splits, slab, slabs);
+    if (pl.splits > 1) {
+        long long maxel = 0;
+        for (int i = 0; i < batch.count; ++i)
+            maxel = std::max(maxel, (long long)batch.p[i].M * batch.p[i].N);
+        int bx = (int)std::min<long long>((maxel + 255) / 256, 1024);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(bx, batch.count),
+                           dim3(256), 0, stream, batch, pl.splits, slab, slabs);
+    }
+    return pcm_check_launch("gemm");
+}
+
+// ---- column sums ---------------------------------------------------------------
+namespace {
+constexpr int CS_ROWS = 256;  // rows per partial block
+
+__global__ __launch_bounds__(256) void colsum_partial_kernel(
+    const float *X, long long ldx, int M, int N, float *partial) {
+    // block (bx, by): columns bx*256 + tid, rows by*CS_ROWS ...
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    float s = 0.0f;
+    for (int r = r0; r < r1; ++r) s += X[(long long)r * ldx + n];
+    partial[(long long)blockIdx.y * N + n] = s;
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(
+    const float *partial, int parts, int N, float *out, const float *alpha_ptr,
+    int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.0f;
+    for (int k = 0; k < parts; ++k) s += partial[(long long)k * N + n];
+    const float alpha = alpha_ptr ? *alpha_ptr : 1.0f;
+    float v = alpha * s;
+    if (accumulate) v += out[n];
+    out[n] = v;
+}
+}  // namespace
+
+size_t pcm_colsum_scratch_bytes(int M, int N) {
+    const int parts = (M + CS_ROWS - 1) / CS_ROWS;
+    return (size_t)parts * N * sizeof(float);
+}
+
+int pcm_colsum_launch(const float *X, long long ldx, int M, int N, float *out,
+                      const float *alpha_ptr, int accumulate, void *scratch,
+                      size_t scratch_bytes, hipStream_t stream) {
+    PCM_REQUIRE(M > 0 && N > 0 && X && out, PCM_EINVAL, "colsum: bad args");
+    PCM_REQUIRE(scratch && scratch_bytes >= pcm_colsum_scratch_bytes(M, N),
+                PCM_ENOMEM, "colsum: scratch too small");
+    const int parts = (M + CS_ROWS - 1) / CS_ROWS;
+    dim3 g1((N + 255) / 256, parts);
+    hipLaunchKernelGGL(colsum_partial_kernel, g1, dim3(256), 0, stream, X, ldx,
+                       M, N, (float *)scratch);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0,
+                       stream, (const float *)scratch, parts, N, out, alpha_ptr,
+                       accumulate);
+    return pcm_check_launch("colsum");
+}

@@ -1,0 +1,323 @@
+// Decoder head and latent kernels: fused softmax / cross-entropy / argmax over
+// every (step, row), reparameterisation, KL divergence, token choice for
+// generation (greedy / temperature sampling) and the Adam update.
+#include "common.h"
+
+namespace {
+
+int grid_for(long long n) {
+    long long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+// active rows per step: cnt[t] = #{b : lengths[b] > t}  (B when lengths == null)
+__global__ __launch_bounds__(256) void step_count_kernel(const int32_t *lengths,
+                                                         int T, int B,
+                                                         float *inv_cnt) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    int c = B;
+    if (lengths) {
+        c = 0;
+        for (int b = 0; b < B; ++b) c += lengths[b] > t ? 1 : 0;
+    }
+    inv_cnt[t] = c > 0 ? 1.0f / (float)c : 0.0f;
+}
+
+// one wave per (t, b) row
+__global__ __launch_bounds__(256) void softmax_ce_kernel(
+    const float *logits, const int64_t *targets, const int32_t *lengths, int T,
+    int B, int V, const float *inv_cnt, float *rowloss, int64_t *argmax,
+    float *dlogits, int32_t *status) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long rows = (long long)T * B;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < rows;
+         row += (long long)gridDim.x * 4) {
+        const int t = (int)(row / B), b = (int)(row - (long long)t * B);
+        const bool active = !lengths || t < lengths[b];
+        const float *x = logits + row * V;
+        if (!active) {
+            if (lane == 0) {
+                rowloss[row] = 0.f;
+                if (argmax) argmax[(long long)b * T + t] = 0;
+            }
+            if (dlogits)
+                for (int v = lane; v < V; v += 64) dlogits[row * V + v] = 0.f;
+            continue;
+        }
+        float m = -INFINITY;
+        int mi = 0x7fffffff;
+        for (int v = lane; v < V; v += 64) {
+            const float xv = x[v];
+            if (xv > m) { m = xv; mi = v; }  // first maximum within the lane
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float om = __shfl_xor(m, off, 64);
+            const int oi = __shfl_xor(mi, off, 64);
+            if (om > m || (om == m && oi < mi)) { m = om; mi = oi; }
+        }
+        float s = 0.f;
+        for (int v = lane; v < V; v += 64) s += expf(x[v] - m);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        const float lse = m + logf(s);
+        long long tg = targets[row];
+        if (tg < 0 || tg >= V) {
+            tg = tg < 0 ? 0 : V - 1;
+            if (status && lane == 0) atomicOr(status, PCM_STATUS_BAD_TOKEN);
+        }
+        const float w = inv_cnt[t];
+        if (lane == 0) {
+            rowloss[row] = (lse - x[tg]) * w;
+            if (argmax) argmax[(long long)b * T + t] = mi;
+        }
+        if (dlogits)
+            for (int v = lane; v < V; v += 64)
+                dlogits[row * V + v] =
+                    (expf(x[v] - lse) - (v == (int)tg ? 1.f : 0.f)) * w;
+    }
+}
+
+// deterministic single-block sum of n floats, scaled
+__global__ __launch_bounds__(1024) void sum_kernel(const float *x, long long n,
+                                                   float scale, float *out) {
+    __shared__ float red[1024];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) s += x[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] * scale;
+}
+
+__global__ __launch_bounds__(256) void reparam_fwd_kernel(
+    const float *mu, const float *logvar, const float *eps, float *z,
+    long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (long long)gridDim.x * 256)
+        z[i] = __fadd_rn(__fmul_rn(eps[i], expf(0.5f * logvar[i])), mu[i]);
+}
+
+__global__ __launch_bounds__(256) void reparam_bwd_kernel(
+    const float *dz, const float *logvar, const float *eps, float *dmu,
+    float *dlogvar, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (long long)gridDim.x * 256) {
+        const float g = dz[i];
+        if (dmu) dmu[i] = g;
+        if (dlogvar) dlogvar[i] = g * eps[i] * 0.5f * expf(0.5f * logvar[i]);
+    }
+}
+
+constexpr int KL_BLOCK = 1024;  // elements per partial
+
+__global__ __launch_bounds__(256) void kl_partial_kernel(const float *mu,
+                                                         const float *logvar,
+                                                         long long n,
+                                                         float *partial) {
+    __shared__ float red[256];
+    const long long base = (long long)blockIdx.x * KL_BLOCK;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < KL_BLOCK; i += 256) {
+        const long long e = base + i;
+        if (e < n) {
+            const float m = mu[e], lv = logvar[e];
+            s += 1.f + lv - m * m - expf(lv);
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void kl_bwd_kernel(const float *dkl,
+                                                     const float *mu,
+                                                     const float *logvar,
+                                                     float *dmu, float *dlogvar,
+                                                     long long n) {
+    const float g = dkl[0];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (long long)gridDim.x * 256) {
+        if (dmu) dmu[i] = g * mu[i];
+        if (dlogvar) dlogvar[i] = g * 0.5f * (expf(logvar[i]) - 1.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(
+    float *param, const float *grad, float *m, float *v, long long n, float lr,
+    float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
+    float grad_scale) {
+    const float step_size = lr / bc1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n;
+         i += (long long)gridDim.x * 256) {
+        const float g = grad[i] * grad_scale;
+        // torch: exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
+        const float mi = m[i] + (g - m[i]) * (1.f - beta1);
+        const float vi = v[i] * beta2 + (1.f - beta2) * g * g;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        param[i] -= step_size * (mi / denom);
+    }
+}
+
+}  // namespace
+
+// token choice for generation: one thread per row ----------------------------
+__global__ __launch_bounds__(256) void choose_token_kernel(
+    const float *logits, int B, int V, int search, float inv_temp,
+    uint64_t seed, int step, int64_t *next_tok, int64_t *tokens_out,
+    long long out_stride, int out_col) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float *x = logits + (long long)b * V;
+    float m = -INFINITY;
+    int mi = 0;
+    for (int v = 0; v < V; ++v) {
+        const float xv = x[v];
+        if (xv > m) { m = xv; mi = v; }
+    }
+    int pick = mi;
+    if (search == PCM_SEARCH_SAMPLING) {
+        // softmax(logits / T), inverse-CDF draw
+        float s = 0.f;
+        for (int v = 0; v < V; ++v) s += expf((x[v] - m) * inv_temp);
+        const float u = pcm_uniform(seed, ((uint64_t)(uint32_t)step << 32) |
+                                              (uint32_t)b) * s;
+        float c = 0.f;
+        pick = V - 1;
+        for (int v = 0; v < V; ++v) {
+            c += expf((x[v] - m) * inv_temp);
+            if (c > u) { pick = v; break; }
+        }
+    }
+    next_tok[b] = pick;
+    tokens_out[(long long)b * out_stride + out_col] = pick;
+}
+
+__global__ __launch_bounds__(256) void broadcast_token_kernel(
+    const int64_t *src, int B, int64_t *next_tok, int64_t *tokens_out,
+    long long out_stride, int out_col) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const int64_t t = src[0];
+    if (next_tok) next_tok[b] = t;
+    if (tokens_out) tokens_out[(long long)b * out_stride + out_col] = t;
+}
+
+int pcm_launch_choose(const float *logits, int B, int V, int search,
+                      float temperature, uint64_t seed, int step,
+                      int64_t *next_tok, int64_t *tokens_out,
+                      long long out_stride, int out_col, hipStream_t stream) {
+    hipLaunchKernelGGL(choose_token_kernel, dim3((B + 255) / 256), dim3(256), 0,
+                       stream, logits, B, V, search, 1.0f / temperature, seed,
+                       step, next_tok, tokens_out, out_stride, out_col);
+    return 0;
+}
+
+int pcm_launch_broadcast_token(const int64_t *src, int B, int64_t *next_tok,
+                               int64_t *tokens_out, long long out_stride,
+                               int out_col, hipStream_t stream) {
+    hipLaunchKernelGGL(broadcast_token_kernel, dim3((B + 255) / 256), dim3(256),
+                       0, stream, src, B, next_tok, tokens_out, out_stride,
+                       out_col);
+    return 0;
+}
+
+extern "C" {
+
+int pcm_softmax_ce(const float *logits, const int64_t *targets,
+                   const int32_t *lengths, int32_t steps, int32_t batch,
+                   int32_t vocab, float *loss, int64_t *argmax, float *dlogits,
+                   float *scratch, int32_t *status, void *stream) {
+    PCM_REQUIRE(logits && targets && loss && scratch, PCM_EINVAL,
+                "softmax_ce: null pointer");
+    PCM_REQUIRE(steps > 0 && batch > 0 && vocab > 0, PCM_EINVAL,
+                "softmax_ce: bad shape T=%d B=%d V=%d", steps, batch, vocab);
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)steps * batch;
+    // scratch: rows row losses followed by `steps` reciprocal counts
+    float *rowloss = scratch;
+    float *inv_cnt = scratch + rows;
+    hipLaunchKernelGGL(step_count_kernel, dim3((steps + 255) / 256), dim3(256),
+                       0, st, lengths, steps, batch, inv_cnt);
+    const int blocks = (int)((rows + 3) / 4 > 8192 ? 8192 : (rows + 3) / 4);
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(blocks), dim3(256), 0, st, logits,
+                       targets, lengths, steps, batch, vocab, inv_cnt, rowloss,
+                       argmax, dlogits, status);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, rowloss, rows,
+                       1.0f, loss);
+    return pcm_check_launch("softmax_ce");
+}
+
+int pcm_reparam_forward(const float *mu, const float *logvar, const float *eps,
+                        float *z, int64_t n, void *stream) {
+    PCM_REQUIRE(mu && logvar && eps && z && n > 0, PCM_EINVAL,
+                "reparam_forward: bad args");
+    hipLaunchKernelGGL(reparam_fwd_kernel, dim3(grid_for(n)), dim3(256), 0,
+                       (hipStream_t)stream, mu, logvar, eps, z, (long long)n);
+    return pcm_check_launch("reparam_forward");
+}
+
+int pcm_reparam_backward(const float *dz, const float *logvar,
+                         const float *eps, float *dmu, float *dlogvar,
+                         int64_t n, void *stream) {
+    PCM_REQUIRE(dz && logvar && eps && n > 0, PCM_EINVAL,
+                "reparam_backward: bad args");
+    hipLaunchKernelGGL(reparam_bwd_kernel, dim3(grid_for(n)), dim3(256), 0,
+                       (hipStream_t)stream, dz, logvar, eps, dmu, dlogvar,
+                       (long long)n);
+    return pcm_check_launch("reparam_backward");
+}
+
+size_t pcm_kl_scratch_floats(int64_t n) {
+    return (size_t)((n + KL_BLOCK - 1) / KL_BLOCK);
+}
+
+int pcm_kl_forward(const float *mu, const float *logvar, float *kl,
+                   float *scratch, int64_t n, void *stream) {
+    PCM_REQUIRE(mu && logvar && kl && scratch && n > 0, PCM_EINVAL,
+                "kl_forward: bad args");
+    const int parts = (int)pcm_kl_scratch_floats(n);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(kl_partial_kernel, dim3(parts), dim3(256), 0, st, mu,
+                       logvar, (long long)n, scratch);
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, scratch,
+                       (long long)parts, -0.5f, kl);
+    return pcm_check_launch("kl_forward");
+}
+
+int pcm_kl_backward(const float *dkl, const float *mu, const float *logvar,
+                    float *dmu, float *dlogvar, int64_t n, void *stream) {
+    PCM_REQUIRE(dkl && mu && logvar && n > 0, PCM_EINVAL,
+                "kl_backward: bad args");
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3(grid_for(n)), dim3(256), 0,
+                       (hipStream_t)stream, dkl, mu, logvar, dmu, dlogvar,
+                       (long long)n);
+    return pcm_check_launch("kl_backward");
+}
+
+int pcm_adam_step(float *param, const float *grad, float *exp_avg,
+                  float *exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, int64_t step, float grad_scale,
+                  void *stream) {
+    PCM_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1,
+                PCM_EINVAL, "adam_step: bad args");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0,
+                       (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
+                       (long long)n, lr, beta1, beta2, eps, (float)bc1,
+                       (float)sqrt(bc2), grad_scale);
+    return pcm_check_launch("adam_step");
+}
+
+}  // extern "C"

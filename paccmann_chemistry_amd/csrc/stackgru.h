@@ -1,0 +1,136 @@
+// Workspace layout and kernel argument blocks of the StackGRU sequence ops.
+#pragma once
+#include "common.h"
+
+// Layout of the caller-provided `saved` workspace (offsets in floats).
+//
+// hidden vectors are stored with row stride Hp = round_up(H, 64) and zero
+// padding so the fused cell kernel streams K in whole 64-wide chunks without
+// bounds checks; the stack top fed to layer 0 likewise with stride Wp.
+struct SGLayout {
+    int B, V, E, H, L, D, W, use_stack;
+    int T, training, dropout;
+    int Hp, Hn, Wp, AVW, DW;
+    int Kx[PCM_MAX_LAYERS];   // width of the non-token GRU input of layer l
+    int Kxp[PCM_MAX_LAYERS];  // ... padded to 64
+    int Kp[PCM_MAX_LAYERS];   // packed K = Kxp + Hp
+    size_t off_hs[PCM_MAX_LAYERS];     // (T+1) x B x Hp ; [0] = initial hidden
+    size_t off_xdrop[PCM_MAX_LAYERS];  // T x B x Hp, dropped input of layer l>=1
+    size_t off_gates[PCM_MAX_LAYERS];  // T x B x 4H : r, z, n, W_hn.h+b_hn
+    size_t off_S;      // training: (T+1) x B x D*W ; else 2 x B x D*W
+    size_t off_av;     // training: T x B x AVW ; else B x AVW  (a[3], v[W])
+    size_t off_xtop;   // training: T x B x Wp ; else B x Wp
+    size_t off_tokg;   // V x 3*Hn   token gate table (b_ih0 folded in)
+    size_t off_wpack[PCM_MAX_LAYERS];  // 3*Hn x Kp[l]
+    size_t off_bpack[PCM_MAX_LAYERS];  // 4*Hn
+    size_t total;      // floats
+
+    size_t hs_step() const { return (size_t)B * Hp; }
+    size_t s_index(int t) const {  // slot holding the stack BEFORE step t
+        return off_S + (size_t)(training ? t : (t & 1)) * B * DW;
+    }
+    size_t av_index(int t) const {
+        return off_av + (size_t)(training ? t : 0) * B * AVW;
+    }
+    size_t xtop_index(int t) const {
+        return off_xtop + (size_t)(training ? t : 0) * B * Wp;
+    }
+};
+
+int pcm_sg_layout(const pcm_dims *dims, int steps, int training, int dropout,
+                  SGLayout *out);
+
+// Layout of the backward `scratch` workspace (offsets in floats).
+struct SGScratch {
+    size_t off_dh;      // L x B x Hp running dL/dh
+    size_t off_dS;      // 2 x B x D*W ping-pong dL/dstack
+    size_t off_dtop;    // B x Wp
+    size_t off_onehot;  // T*B x V  one-hot of the input tokens
+    size_t off_dtokg;   // V x 3H   gradient of the token gate table
+    size_t off_tmp;     // 3H x E   scratch product
+    size_t off_gemm;    // split-K slabs / column-sum partials
+    size_t gemm_bytes;
+    size_t total;       // floats
+};
+int pcm_sg_scratch(const SGLayout &lay, SGScratch *out);
+
+// ---- kernel launchers (stackgru_fwd.hip / stackgru_bwd.hip) ------------------
+struct CellFwdArgs {
+    const float *xin;   // [B, ldx] non-token input (stack top / lower layer)
+    const float *hprev; // [B, Hp]
+    const float *wpack; // [3*Hn, Kp]
+    const float *bpack; // [4*Hn]
+    const float *tokg;  // [V, 3*Hn] or null (layers >= 1)
+    const int64_t *tok; // [B] or null
+    float *hnew;        // [B, Hp]
+    float *gates;       // [B, 4H] or null
+    float *xdrop;       // [B, Hp] or null: dropout(hnew) for the next layer
+    const int32_t *lengths;
+    int32_t *status;
+    int ldx, nx_chunks, nh_chunks, Kp;
+    int B, H, Hn, Hp, V, t, next_layer;
+    float drop_p, inv_keep;
+    uint64_t seed;
+};
+int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream);
+
+struct StackFwdArgs {
+    const float *htop;   // [B, Hp] top-layer hidden before the step
+    const float *S_prev; // [B, D*W]
+    float *S_new;        // [B, D*W]
+    const float *ctrl_w, *ctrl_b, *push_w, *push_b;
+    float *av;           // [B, AVW]
+    float *xtop;         // [B, Wp]
+    const int32_t *lengths;
+    int B, H, Hp, D, W, Wp, AVW, t;
+};
+int pcm_launch_stack_fwd(const StackFwdArgs &a, hipStream_t stream);
+
+struct PackArgs {
+    const float *w_ih, *w_hh, *b_ih, *b_hh;
+    float *wpack, *bpack;
+    int H, Hn, Hp, Kx, Kxp, Kp, ld_ih, x_off, fold_bih;
+};
+int pcm_launch_pack(const PackArgs &a, hipStream_t stream);
+
+// hs[l][0] <- h0 (or 0), with zero padding; S[0] <- stack0 (or 0)
+int pcm_launch_init_state(const SGLayout &lay, float *saved, const float *h0,
+                          long long h0_layer_stride, const float *stack0,
+                          hipStream_t stream);
+// h_final / stack_final extraction (strided copy)
+int pcm_launch_copy_rows(const float *src, long long lds, float *dst,
+                         long long ldd, int rows, int cols,
+                         hipStream_t stream);
+
+struct GateBwdArgs {
+    float *dh;            // [B, Hp] in: dL/dh_t ; out: dL/dh_{t-1} direct part
+    const float *dout;    // [B, ld_dout] extra gradient of h_t or null
+    float *gates;         // [B, 4H] in: r,z,n,ghn ; out: dr,dz,dni,dnh
+    const float *hprev;   // [B, Hp]
+    const int32_t *lengths;
+    long long ld_dout;
+    int B, H, Hp, t;
+};
+int pcm_launch_gate_bwd(const GateBwdArgs &a, hipStream_t stream);
+
+struct StackBwdArgs {
+    const float *dS_next; // [B, D*W] dL/dS'_t (null = zeros)
+    float *dS_prev;       // [B, D*W] dL/dS_{t-1}
+    const float *dtop;    // [B, Wp] gradient of the stack top fed to layer 0
+    const float *S_prev;  // [B, D*W]
+    float *av;            // [B, AVW] in: a,v ; out: dc, du
+    const float *ctrl_w, *push_w;
+    float *dh_top;        // [B, Hp] += dc.Wc + du.Ws
+    const int32_t *lengths;
+    int B, H, Hp, D, W, Wp, AVW, t;
+};
+int pcm_launch_stack_bwd(const StackBwdArgs &a, hipStream_t stream);
+
+// x[b][j] *= dropout multiplier of (seed, layer, t, b, j)
+int pcm_launch_dropout_mask_mul(float *x, long long ldx, int B, int H,
+                                uint64_t seed, int layer, int t, float p,
+                                hipStream_t stream);
+// out[row][v] = (tokens[row] == v)
+int pcm_launch_onehot(const int64_t *tokens, long long rows, int V, float *out,
+                      hipStream_t stream);
+int pcm_launch_fill(float *dst, float value, long long n, hipStream_t stream);

@@ -1,0 +1,412 @@
+// Forward kernels of the StackGRU recurrence (stack_rnn.py:131-232).
+//
+// Per time step:
+//   stack_step_fwd  a = softmax(Wc.h_top+bc), v = tanh(Ws.h_top+bs), the fused
+//                   push/pop/no-op update of the [D,W] stack (1 read + 1 write
+//                   of the stack, HBM-bound) and the stack top for layer 0
+//   gru_cell_fwd    one GRU layer: [x | h] . Wpack^T on fp32 MFMA (32x32x2),
+//                   LDS-staged 64-wide K chunks, intra-block split-K over the
+//                   4 waves, gate math + token-gate gather in the epilogue
+#include "stackgru.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------
+// fused GRU cell
+// ------------------------------------------------------------------------------
+constexpr int CK = 64;        // K per chunk
+constexpr int LDT = CK + 4;   // LDS row stride in floats (272 B: conflict-free b128)
+constexpr int CM = 32;        // batch rows per block
+constexpr int CN = 32;        // hidden units per block (x3 gates)
+constexpr int A_TILE = CM * LDT;
+constexpr int W_TILE = 3 * CN * LDT;
+constexpr int CELL_LDS = 2 * (A_TILE + W_TILE);  // floats (69632 B)
+static_assert(CELL_LDS >= 4 * 4 * 1024, "reduction buffer must fit");
+
+__global__ __launch_bounds__(256) void gru_cell_fwd_kernel(CellFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[CELL_LDS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int j0 = blockIdx.x * CN;   // first hidden unit of the tile
+    const int b0 = blockIdx.y * CM;   // first batch row
+    const int nchunks = a.nx_chunks + a.nh_chunks;
+
+    // staging registers: A tile 2 x float4, W tile 6 x float4 per thread
+    f32x4 ra[2], rw[6];
+    auto load_chunk = [&](int c) {
+        const bool xpart = c < a.nx_chunks;
+        const float *src = xpart ? a.xin : a.hprev;
+        const int ld = xpart ? a.ldx : a.Hp;
+        const int kb = (xpart ? c : c - a.nx_chunks) * CK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 4, q = idx & 15;
+            const int b = b0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b < a.B)
+                v = *(const f32x4 *)(src + (long long)b * ld + kb + q * 4);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 4, q = idx & 15;  // row 0..95
+            const int g = row >> 5, jj = row & 31;
+            rw[i] = *(const f32x4 *)(a.wpack +
+                                     (long long)(g * a.Hn + j0 + jj) * a.Kp +
+                                     c * CK + q * 4);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float *As = lds + buf * (A_TILE + W_TILE);
+        float *Ws = As + A_TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            *(f32x4 *)(As + (idx >> 4) * LDT + (idx & 15) * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int idx = tid + 256 * i;
+            *(f32x4 *)(Ws + (idx >> 4) * LDT + (idx & 15) * 4) = rw[i];
+        }
+    };
+
+    f32x16 acc_r, acc_z, acc_ni, acc_nh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc_r[r] = 0.f; acc_z[r] = 0.f; acc_ni[r] = 0.f; acc_nh[r] = 0.f;
+    }
+
+    const int lrow = lane & 31, lh = lane >> 5;
+    load_chunk(0);
+    int buf = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        store_chunk(buf);
+        __syncthreads();
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        const float *As = lds + buf * (A_TILE + W_TILE);
+        const float *Ws = As + A_TILE;
+        // this wave's 16-wide k slice; lane half lh supplies k = 8s + 4*lh + e
+        const int koff = wave * 16 + 4 * lh;
+        f32x4 fa[2], fr[2], fz[2], fn[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            fa[s] = *(const f32x4 *)(As + lrow * LDT + koff + 8 * s);
+            fr[s] = *(const f32x4 *)(Ws + (0 * CN + lrow) * LDT + koff + 8 * s);
+            fz[s] = *(const f32x4 *)(Ws + (1 * CN + lrow) * LDT + koff + 8 * s);
+            fn[s] = *(const f32x4 *)(Ws + (2 * CN + lrow) * LDT + koff + 8 * s);
+        }
+        if (c < a.nx_chunks) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[s][e], fr[s][e], acc_r, 0, 0, 0);
+                    acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[s][e], fz[s][e], acc_z, 0, 0, 0);
+                    acc_ni = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[s][e], fn[s][e], acc_ni, 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[s][e], fr[s][e], acc_r, 0, 0, 0);
+                    acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[s][e], fz[s][e], acc_z, 0, 0, 0);
+                    acc_nh = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[s][e], fn[s][e], acc_nh, 0, 0, 0);
+                }
+        }
+        buf ^= 1;
+    }
+
+    // cross-wave reduction of the 4 partial tiles through LDS
+    __syncthreads();
+    float *red = lds;  // [wave][tile][32][32]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float *base = red + (wave * 4) * 1024 + row * 32 + lrow;
+        base[0 * 1024] = acc_r[r];
+        base[1 * 1024] = acc_z[r];
+        base[2 * 1024] = acc_ni[r];
+        base[3 * 1024] = acc_nh[r];
+    }
+    __syncthreads();
+
+    const int H = a.H, Hn = a.Hn;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q;
+        const int row = e >> 5, col = e & 31;
+        const int b = b0 + row, j = j0 + col;
+        float s[4];
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[(w * 4 + tl) * 1024 + e];
+            s[tl] = v;
+        }
+        if (b >= a.B || j >= H) continue;
+        float tr = 0.f, tz = 0.f, tn = 0.f;
+        if (a.tokg) {
+            long long tk = a.tok[b];
+            if (tk < 0 || tk >= a.V) {
+                tk = tk < 0 ? 0 : a.V - 1;
+                if (a.status) atomicOr(a.status, PCM_STATUS_BAD_TOKEN);
+            }
+            const float *tg = a.tokg + tk * (3LL * Hn);
+            tr = tg[j]; tz = tg[Hn + j]; tn = tg[2 * Hn + j];
+        }
+        const float r_ = pcm_sigmoid(s[0] + a.bpack[j] + tr);
+        const float z_ = pcm_sigmoid(s[1] + a.bpack[Hn + j] + tz);
+        const float ghn = s[3] + a.bpack[3 * Hn + j];
+        const float n_ = tanhf(s[2] + a.bpack[2 * Hn + j] + tn + r_ * ghn);
+        const float hp = a.hprev[(long long)b * a.Hp + j];
+        // ATen GRU cell: (h - n) * z + n
+        float hn = __fadd_rn(__fmul_rn(hp - n_, z_), n_);
+        if (a.lengths && a.t >= a.lengths[b]) hn = hp;
+        a.hnew[(long long)b * a.Hp + j] = hn;
+        if (a.gates) {
+            float *g = a.gates + (long long)b * 4 * H;
+            g[j] = r_; g[H + j] = z_; g[2 * H + j] = n_; g[3 * H + j] = ghn;
+        }
+        if (a.xdrop)
+            a.xdrop[(long long)b * a.Hp + j] =
+                hn * pcm_dropout_scale(a.seed, a.next_layer, a.t, b, j,
+                                       a.drop_p, a.inv_keep);
+    }
+}
+
+// ------------------------------------------------------------------------------
+// stack controls + fused stack update
+// ------------------------------------------------------------------------------
+constexpr int SROWS = 4;  // batch rows per block
+
+__global__ __launch_bounds__(256) void stack_step_fwd_kernel(StackFwdArgs a) {
+    extern __shared__ float sm[];
+    float *hrow = sm;                         // [SROWS][H]
+    float *cu = sm + SROWS * a.H;             // [SROWS][AVW] pre-activations -> a, v
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b0 = blockIdx.x * SROWS;
+    const int H = a.H, W = a.W, D = a.D, DW = D * W, NO = 3 + W;
+
+    for (int idx = tid; idx < SROWS * H; idx += 256) {
+        const int r = idx / H, k = idx - r * H;
+        const int b = b0 + r;
+        hrow[idx] = b < a.B ? a.htop[(long long)b * a.Hp + k] : 0.f;
+    }
+    __syncthreads();
+
+    // dot products: wave handles outputs o = wave, wave+4, ...; lanes stride K
+    for (int o = wave; o < NO; o += 4) {
+        const float *wrow = o < 3 ? a.ctrl_w + (long long)o * H
+                                  : a.push_w + (long long)(o - 3) * H;
+        float p[SROWS];
+#pragma unroll
+        for (int r = 0; r < SROWS; ++r) p[r] = 0.f;
+        for (int k = lane; k < H; k += 64) {
+            const float w = wrow[k];
+#pragma unroll
+            for (int r = 0; r < SROWS; ++r) p[r] = fmaf(w, hrow[r * H + k], p[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < SROWS; ++r) {
+            float v = p[r];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            p[r] = v;
+        }
+        if (lane == 0) {
+            const float bias = o < 3 ? a.ctrl_b[o] : a.push_b[o - 3];
+#pragma unroll
+            for (int r = 0; r < SROWS; ++r) cu[r * a.AVW + o] = p[r] + bias;
+        }
+    }
+    __syncthreads();
+
+    // softmax over the 3 controls (one thread per row), tanh of the push value
+    if (tid < SROWS) {
+        float *c = cu + tid * a.AVW;
+        const float m = fmaxf(c[0], fmaxf(c[1], c[2]));
+        const float e0 = expf(c[0] - m), e1 = expf(c[1] - m), e2 = expf(c[2] - m);
+        const float s = e0 + e1 + e2;
+        c[0] = e0 / s; c[1] = e1 / s; c[2] = e2 / s;
+    }
+    for (int idx = tid; idx < SROWS * W; idx += 256) {
+        const int r = idx / W, w = idx - r * W;
+        cu[r * a.AVW + 3 + w] = tanhf(cu[r * a.AVW + 3 + w]);
+    }
+    __syncthreads();
+
+    // record a, v (needed by the reverse pass) and update the stack
+    for (int idx = tid; idx < SROWS * a.AVW; idx += 256) {
+        const int r = idx / a.AVW, o = idx - r * a.AVW;
+        const int b = b0 + r;
+        if (b < a.B) a.av[(long long)b * a.AVW + o] = o < NO ? cu[idx] : 0.f;
+    }
+    for (int idx = tid; idx < SROWS * DW; idx += 256) {
+        const int r = idx / DW, e = idx - r * DW;
+        const int b = b0 + r;
+        if (b >= a.B) continue;
+        const int d = e / W, w = e - d * W;
+        const float *Sp = a.S_prev + (long long)b * DW;
+        const float s = Sp[e];
+        float nv = s;
+        if (!(a.lengths && a.t >= a.lengths[b])) {
+            const float *c = cu + r * a.AVW;
+            const float up = d == 0 ? c[3 + w] : Sp[e - W];
+            const float dn = d == D - 1 ? 0.f : Sp[e + W];
+            // reference order: no_op*S, + push*up, + pop*down (stack_rnn.py:229-231)
+            nv = __fadd_rn(__fadd_rn(__fmul_rn(c[2], s), __fmul_rn(c[0], up)),
+                           __fmul_rn(c[1], dn));
+        }
+        a.S_new[(long long)b * DW + e] = nv;
+        if (d == 0) a.xtop[(long long)b * a.Wp + w] = nv;
+    }
+    const int padw = a.Wp - W;
+    for (int idx = tid; idx < SROWS * padw; idx += 256) {
+        const int r = idx / padw, w = W + idx - r * padw;
+        const int b = b0 + r;
+        if (b < a.B) a.xtop[(long long)b * a.Wp + w] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------
+// weight packing, state init, copies
+// ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
+    // wpack[(g*Hn + j)*Kp + k]
+    const long long total = 3LL * a.Hn * a.Kp;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * 256) {
+        const int k = (int)(idx % a.Kp);
+        const int row = (int)(idx / a.Kp);
+        const int g = row / a.Hn, j = row - g * a.Hn;
+        float v = 0.f;
+        if (j < a.H) {
+            if (k < a.Kxp) {
+                if (k < a.Kx)
+                    v = a.w_ih[(long long)(g * a.H + j) * a.ld_ih + a.x_off + k];
+            } else {
+                const int kk = k - a.Kxp;
+                if (kk < a.H) v = a.w_hh[(long long)(g * a.H + j) * a.H + kk];
+            }
+        }
+        a.wpack[idx] = v;
+    }
+    // bpack[q*Hn + j]: q=0 r, 1 z, 2 n (input side), 3 n (hidden side)
+    if (blockIdx.x == 0) {
+        for (int idx = threadIdx.x; idx < 4 * a.Hn; idx += 256) {
+            const int q = idx / a.Hn, j = idx - q * a.Hn;
+            float v = 0.f;
+            if (j < a.H) {
+                const float bi_r = a.fold_bih ? 0.f : a.b_ih[j];
+                const float bi_z = a.fold_bih ? 0.f : a.b_ih[a.H + j];
+                const float bi_n = a.fold_bih ? 0.f : a.b_ih[2 * a.H + j];
+                if (q == 0) v = bi_r + a.b_hh[j];
+                else if (q == 1) v = bi_z + a.b_hh[a.H + j];
+                else if (q == 2) v = bi_n;
+                else v = a.b_hh[2 * a.H + j];
+            }
+            a.bpack[idx] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float *src,
+                                                        long long lds_,
+                                                        float *dst,
+                                                        long long ldd, int rows,
+                                                        int cols, int dst_cols) {
+    // copies [rows, cols]; columns cols..dst_cols-1 of dst are zero-filled
+    const long long total = (long long)rows * dst_cols;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * 256) {
+        const int c = (int)(idx % dst_cols);
+        const long long r = idx / dst_cols;
+        float v = 0.f;
+        if (c < cols && src) v = src[r * lds_ + c];
+        dst[r * ldd + c] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float *dst, float value,
+                                                   long long n) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n;
+         idx += (long long)gridDim.x * 256)
+        dst[idx] = value;
+}
+
+int grid_for(long long n) {
+    long long g = (n + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
+    dim3 grid(a.Hn / CN, (a.B + CM - 1) / CM);
+    hipLaunchKernelGGL(gru_cell_fwd_kernel, grid, dim3(256), 0, stream, a);
+    return 0;
+}
+
+int pcm_launch_stack_fwd(const StackFwdArgs &a, hipStream_t stream) {
+    const size_t lds = (size_t)SROWS * (a.H + a.AVW) * sizeof(float);
+    PCM_REQUIRE(lds <= 64 * 1024, PCM_EINVAL,
+                "stack step: hidden size %d too large for the LDS row cache",
+                a.H);
+    dim3 grid((a.B + SROWS - 1) / SROWS);
+    hipLaunchKernelGGL(stack_step_fwd_kernel, grid, dim3(256), lds, stream, a);
+    return 0;
+}
+
+int pcm_launch_pack(const PackArgs &a, hipStream_t stream) {
+    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(3LL * a.Hn * a.Kp)),
+                       dim3(256), 0, stream, a);
+    return 0;
+}
+
+int pcm_launch_copy_rows(const float *src, long long lds_, float *dst,
+                         long long ldd, int rows, int cols,
+                         hipStream_t stream) {
+    hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((long long)rows * cols)),
+                       dim3(256), 0, stream, src, lds_, dst, ldd, rows, cols,
+                       cols);
+    return 0;
+}
+
+int pcm_launch_fill(float *dst, float value, long long n, hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(256), 0, stream, dst,
+                       value, n);
+    return 0;
+}
+
+int pcm_launch_init_state(const SGLayout &lay, float *saved, const float *h0,
+                          long long h0_layer_stride, const float *stack0,
+                          hipStream_t stream) {
+    for (int l = 0; l < lay.L; ++l) {
+        const float *src = h0 ? h0 + (long long)l * h0_layer_stride : nullptr;
+        float *dst = saved + lay.off_hs[l];
+        hipLaunchKernelGGL(copy_rows_kernel,
+                           dim3(grid_for((long long)lay.B * lay.Hp)), dim3(256),
+                           0, stream, src, (long long)lay.H, dst,
+                           (long long)lay.Hp, lay.B, lay.H, lay.Hp);
+    }
+    if (lay.use_stack) {
+        float *dst = saved + lay.s_index(0);
+        hipLaunchKernelGGL(copy_rows_kernel,
+                           dim3(grid_for((long long)lay.B * lay.DW)), dim3(256),
+                           0, stream, stack0, (long long)lay.DW, dst,
+                           (long long)lay.DW, lay.B, lay.DW, lay.DW);
+    }
+    return 0;
+}

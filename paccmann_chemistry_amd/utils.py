@@ -1,0 +1,164 @@
+"""Host-side helpers either side of the hot path: device selection, batch
+preparation (padded / packed) and the KL annealing weight.  Mirrors the names
+exported by the reference's ``paccmann_chemistry/utils/__init__.py``; the
+rdkit / pytoda dependent cosmetics are not part of this path.
+"""
+import math
+
+import torch
+from torch.nn.utils.rnn import (
+    PackedSequence, pack_sequence, pad_packed_sequence
+)
+
+
+def cuda():
+    return torch.cuda.is_available()
+
+
+def get_device():
+    """utils/utils.py:18-19."""
+    return torch.device('cuda' if cuda() else 'cpu')
+
+
+def kl_weight(step, growth_rate=0.004):
+    """Sigmoid KL annealing weight (utils/utils.py:246-264)."""
+    return 1 / (1 + math.exp((15 - growth_rate * step)))
+
+
+def _dropout_rows(shape_rows, input_keep):
+    """Bernoulli(keep) per position, 1 = keep (utils/utils.py:71,127)."""
+    return torch.bernoulli(torch.full((shape_rows, ), float(input_keep)))
+
+
+def sequential_data_preparation(
+    input_batch, input_keep=1, start_index=2, end_index=3, dropout_index=1,
+    device=None
+):
+    """Padded mode (utils/utils.py:29-81): returns (encoder_seq, decoder_seq,
+    target_seq), each i64[T,B].  Word dropout replaces WHOLE time rows of the
+    decoder input by ``dropout_index`` (<UNK>); the target is the input shifted
+    by one step with a zero row appended."""
+    device = get_device() if device is None else device
+    input_batch = input_batch.long().to(device)
+    decoder_batch = input_batch.clone()
+    if input_keep != 1:
+        keep = _dropout_rows(input_batch.shape[0], input_keep).to(device)
+        decoder_batch[keep == 0] = dropout_index
+    end_padding = torch.zeros(
+        1, input_batch.shape[1], dtype=torch.long, device=device
+    )
+    target_seq = torch.cat((input_batch[1:], end_padding), dim=0)
+    return input_batch, decoder_batch, target_seq
+
+
+def packed_sequential_data_preparation(
+    input_batch, input_keep=1, start_index=2, end_index=3, dropout_index=1,
+    device=None
+):
+    """Packed mode (utils/utils.py:84-146): ``input_batch`` is a list of 1-D
+    token tensors sorted by length (longest first); word dropout is applied
+    per token; returns three ``PackedSequence`` objects."""
+    device = get_device() if device is None else device
+    enc, dec, tgt = [], [], []
+    for sample in input_batch:
+        if sample.dim() != 1:
+            raise ValueError
+        inp = sample.long().to(device)
+        decoder = inp.clone()
+        if input_keep != 1:
+            keep = _dropout_rows(inp.shape[0], input_keep).to(device)
+            decoder[keep == 0] = dropout_index
+        target = torch.cat(
+            [inp[1:], torch.zeros(1, dtype=torch.long, device=device)]
+        )
+        enc.append(inp)
+        dec.append(decoder)
+        tgt.append(target)
+    return [pack_sequence(entry) for entry in (enc, dec, tgt)]
+
+
+def collate_fn(batch):
+    """Sort a batch from longest to shortest (utils/utils.py:149-168)."""
+    order = sorted(
+        range(len(batch)), key=lambda i: batch[i].shape[0], reverse=True
+    )
+    return [batch[i] for i in order]
+
+
+def unpack_sequence(seq):
+    tensor_seqs, seq_lens = pad_packed_sequence(seq)
+    return [s[:n] for s, n in zip(tensor_seqs.unbind(dim=1), seq_lens)]
+
+
+def repack_sequence(seq):
+    return pack_sequence(seq)
+
+
+def perpare_packed_input(input):  # (sic) reference spelling
+    """Split PackedSequence.data by batch_sizes (utils/utils.py:215-223)."""
+    data, prev = [], 0
+    for batch in input.batch_sizes:
+        size = prev + int(batch)
+        data.append(input.data[prev:size])
+        prev = size
+    return data, input.batch_sizes
+
+
+def manage_step_packed_vars(final_var, var, batch_size, prev_batch, batch_dim):
+    """utils/utils.py:226-243 (kept for API compatibility; the fused kernels
+    honour packed semantics through per-row lengths instead)."""
+    if batch_size < prev_batch:
+        finished = int(prev_batch - batch_size)
+        brk = var.shape[batch_dim] - finished
+        if batch_dim == 0:
+            if final_var is not None:
+                final_var[brk:] = var[brk:]
+            var = var[:brk]
+        elif batch_dim == 1:
+            if final_var is not None:
+                final_var[:, brk:] = var[:, brk:]
+            var = var[:, :brk]
+        else:
+            raise ValueError('Allowed batch dim are 1 and 2')
+    return final_var, var
+
+
+def packed_to_lengths(packed):
+    """PackedSequence -> (padded i64[T,B] on the data's device, lengths
+    i64[B] on CPU).  Requires the length-sorted layout ``pack_sequence``
+    produces (enforce_sorted), which is what the reference's loops assume."""
+    if not isinstance(packed, PackedSequence):
+        raise TypeError('Input is not PackedSequence')
+    if packed.sorted_indices is not None:
+        idx = packed.sorted_indices.cpu()
+        if not torch.equal(idx, torch.arange(len(idx))):
+            raise ValueError(
+                'PackedSequence must be built from length-sorted sequences'
+            )
+    padded, lengths = pad_packed_sequence(packed)
+    return padded, lengths
+
+
+def to_np(x):
+    return x.data.cpu().numpy()
+
+
+def crop_start_stop(smiles, smiles_language):
+    """utils/utils.py:271-284."""
+    smiles = smiles.tolist()
+    try:
+        start_idx = smiles.index(smiles_language.start_index)
+        stop_idx = smiles.index(smiles_language.stop_index)
+        return smiles[start_idx + 1:stop_idx]
+    except Exception:
+        return smiles
+
+
+def crop_start(smiles, smiles_language):
+    """utils/utils.py:287-299."""
+    smiles = smiles.tolist()
+    try:
+        start_idx = smiles.index(smiles_language.start_index)
+        return smiles[start_idx + 1:]
+    except Exception:
+        return smiles

@@ -1,0 +1,434 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference's golden
+vectors and against the CPU oracle on the same seeded inputs.
+
+Tolerances (north star): per-step fp32 logits within 1e-4 relative (to the
+largest logit), loss within 1e-5 relative, gradients within 1e-4 of the
+largest entry of each parameter gradient; greedy tokens and argmax bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Golden, golden_names
+from oracle import stackgru_oracle as O
+from oracle import weights as W
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-4
+GRAD_TOL = 1e-4
+
+
+def _dev():
+    return torch.device('cuda:0')
+
+
+def _rel_to_max(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).abs().max() / b.abs().max().clamp(min=1e-12)).item()
+
+
+def _build_vae(params, weights, train=True):
+    import paccmann_chemistry_amd as P
+    p = dict(params)
+    vae = P.TeacherVAE(P.StackGRUEncoder(p), P.StackGRUDecoder(p))
+    missing = vae.load_state_dict(
+        {k: v.clone() for k, v in weights.items()}, strict=True
+    )
+    assert not missing.missing_keys and not missing.unexpected_keys
+    vae = vae.to(_dev())
+    vae.train(train)
+    return vae
+
+
+def _inputs(g, vae):
+    dev = _dev()
+    tokens, dec_tokens = g.tensor('tokens'), g.tensor('dec_tokens')
+    targets = g.tensor('targets')
+    if g.lengths is None:
+        return tokens.to(dev), dec_tokens.to(dev), targets.to(dev)
+    pack = torch.nn.utils.rnn.pack_sequence
+    lens = g.lengths.tolist()
+    enc = pack([tokens[:n, b].to(dev) for b, n in enumerate(lens)])
+    dec = pack([dec_tokens[:n, b].to(dev) for b, n in enumerate(lens)])
+    tgt = pack([targets[:n, b].to(dev) for b, n in enumerate(lens)])
+    return enc, dec, tgt
+
+
+def _run_gpu_vae(g):
+    from paccmann_chemistry_amd import vae_loss_function
+    p = dict(g.params)
+    p['dropout'] = 0.0
+    vae = _build_vae(p, g.weights)
+    enc, dec, tgt = _inputs(g, vae)
+    eps = g.tensor('eps').to(_dev())
+    dec_loss, mu, logvar = vae(enc, dec, tgt, eps=eps)
+    total, kl = vae_loss_function(
+        dec_loss, mu, logvar, kl_growth=float(g.data['kl_growth']),
+        step=int(g.data['step'])
+    )
+    total.backward()
+    vae.check_tokens()
+    return vae, dec_loss, mu, logvar, total, kl
+
+
+def _masked_logits(g, logits):
+    ref = g.tensor('logits')
+    logits = logits.detach().cpu()
+    if g.lengths is not None:
+        steps = torch.arange(ref.shape[0]).view(-1, 1)
+        active = (g.lengths.view(1, -1) > steps).unsqueeze(-1)
+        logits = logits * active
+    return logits, ref
+
+
+# --------------------------------------------------------------------------
+def test_library_reports_gfx950():
+    from paccmann_chemistry_amd import _lib
+    lib = _lib.load()
+    torch.zeros(1, device=_dev())
+    assert lib.pcm_device_check() == 0, lib.pcm_last_error()
+
+
+@pytest.mark.parametrize(
+    'm,n,k', [(1, 1, 1), (3, 5, 7), (64, 64, 16), (70, 33, 129),
+              (512, 60, 512), (257, 1536, 110), (1000, 50, 50)]
+)
+def test_linear_forward_backward(m, n, k):
+    """The generic MFMA GEMM behind every dense product (odd sizes, all three
+    operand layouts, split-K) against an fp64 torch product."""
+    from paccmann_chemistry_amd.ops import linear
+    gen = torch.Generator().manual_seed(m * 131 + n * 17 + k)
+    x = torch.randn(m, k, generator=gen)
+    w = torch.randn(n, k, generator=gen)
+    b = torch.randn(n, generator=gen)
+    dy = torch.randn(m, n, generator=gen)
+    xd = x.to(_dev()).requires_grad_(True)
+    wd = w.to(_dev()).requires_grad_(True)
+    bd = b.to(_dev()).requires_grad_(True)
+    y = linear(xd, wd, bd)
+    y.backward(dy.to(_dev()))
+    x64, w64, b64 = x.double(), w.double(), b.double()
+    assert _rel_to_max(y, x64 @ w64.t() + b64) < 2e-6
+    assert _rel_to_max(xd.grad, dy.double() @ w64) < 2e-6
+    assert _rel_to_max(wd.grad, dy.double().t() @ x64) < 2e-6
+    assert _rel_to_max(bd.grad, dy.double().sum(0)) < 2e-6
+
+
+def test_linear_large_k_splitk():
+    """Weight-gradient shape of the path: K = T*B rows reduced by split-K."""
+    from paccmann_chemistry_amd.ops import linear
+    gen = torch.Generator().manual_seed(5)
+    m, n, k = 6000, 96, 40
+    x = torch.randn(m, k, generator=gen)
+    w = torch.randn(n, k, generator=gen)
+    dy = torch.randn(m, n, generator=gen)
+    xd = x.to(_dev())
+    wd = w.to(_dev()).requires_grad_(True)
+    y = linear(xd, wd, None)
+    y.backward(dy.to(_dev()))
+    assert _rel_to_max(wd.grad, dy.double().t() @ x.double()) < 3e-6
+    first = wd.grad.clone()
+    wd.grad = None
+    linear(xd, wd, None).backward(dy.to(_dev()))
+    assert torch.equal(first, wd.grad)  # deterministic reduction order
+
+
+@pytest.mark.parametrize('name', golden_names('step_'))
+def test_single_step_golden(name):
+    """StackGRU.forward for one token with non-zero incoming state."""
+    from paccmann_chemistry_amd import StackGRU
+    g = Golden(name)
+    p = dict(g.params)
+    p['dropout'] = 0.0
+    cell = StackGRU(p)
+    cell.load_state_dict({k: v.clone() for k, v in g.weights.items()})
+    cell = cell.to(_dev()).eval()
+    with torch.no_grad():
+        out, hid, stack = cell(
+            g.tensor('token').to(_dev()), g.tensor('hidden').to(_dev()),
+            g.tensor('stack').to(_dev())
+        )
+    assert _rel_to_max(out, g.data['output']) < 2e-6
+    assert _rel_to_max(hid, g.data['hidden_out']) < 2e-6
+    assert _rel_to_max(stack, g.data['stack_out']) < 2e-6
+
+
+@pytest.mark.parametrize(
+    'name', [n for n in golden_names('vae_') if 'config' not in n]
+)
+def test_vae_small_golden(name):
+    g = Golden(name)
+    vae, dec_loss, mu, logvar, total, kl = _run_gpu_vae(g)
+    assert _rel_to_max(mu, g.data['mu']) < 1e-5
+    assert _rel_to_max(logvar, g.data['logvar']) < 1e-5
+    logits, ref = _masked_logits(g, vae.decoder.logits)
+    assert _rel_to_max(logits, ref) < LOGIT_TOL
+    assert abs(dec_loss.item() - float(g.data['decoder_loss'])) <= \
+        1e-5 * abs(float(g.data['decoder_loss']))
+    assert abs(kl.item() - float(g.data['kl'])) <= 1e-5 * abs(
+        float(g.data['kl']))
+    assert abs(total.item() - float(g.data['loss'])) <= 1e-5 * abs(
+        float(g.data['loss']))
+    outputs = vae.decoder.outputs.cpu().numpy().astype(np.int64)
+    assert np.array_equal(outputs, g.data['outputs'].astype(np.int64))
+    named = dict(vae.named_parameters())
+    for key, ref_grad in g.grads.items():
+        assert named[key].grad is not None, key
+        err = _rel_to_max(named[key].grad, ref_grad)
+        assert err < GRAD_TOL, (key, err)
+    for key, param in named.items():
+        if key not in g.grads:
+            assert param.grad is None or param.grad.abs().max().item() == 0, key
+
+
+@pytest.mark.parametrize('name', golden_names('vae_config'))
+def test_vae_config_golden(name):
+    """H=512, V=60, D=W=50, L=2, Z=256, T=120 against the reference."""
+    g = Golden(name)
+    vae, dec_loss, mu, logvar, total, kl = _run_gpu_vae(g)
+    logits, ref = _masked_logits(g, vae.decoder.logits)
+    assert _rel_to_max(logits, ref) < LOGIT_TOL
+    assert abs(dec_loss.item() - float(g.data['decoder_loss'])) <= \
+        1e-5 * abs(float(g.data['decoder_loss']))
+    assert abs(kl.item() - float(g.data['kl'])) <= 1e-4 * abs(
+        float(g.data['kl']))
+    outputs = vae.decoder.outputs.cpu().numpy().astype(np.int64)
+    assert np.array_equal(outputs, g.data['outputs'].astype(np.int64))
+    named = dict(vae.named_parameters())
+    for key, norm in g.grad_norms.items():
+        got = named[key].grad.double().norm().item()
+        assert abs(got - norm) <= 2e-4 * max(norm, 1e-8), (key, got, norm)
+        sample = named[key].grad.reshape(-1)[::997]
+        assert _rel_to_max(sample, g.grad_samples[key]) < 2e-4, key
+
+
+@pytest.mark.parametrize('name', golden_names('greedy_'))
+def test_greedy_decode_golden(name):
+    """Greedy tokens bit-exact, per-step logits within tolerance."""
+    from paccmann_chemistry_amd import GreedySearch
+    g = Golden(name)
+    p = dict(g.params)
+    vae = _build_vae(p, g.weights, train=False)
+    tokens, logits = vae.decoder.generate_from_latent(
+        g.tensor('z').to(_dev()), g.tensor('prime').to(_dev()),
+        torch.tensor([3]), search=GreedySearch(),
+        generate_len=int(g.data['generate_len']), return_logits=True
+    )
+    assert _rel_to_max(logits, g.data['logits']) < LOGIT_TOL
+    assert np.array_equal(tokens.cpu().numpy(), g.data['tokens'])
+
+
+def test_determinism_bitwise():
+    """Same inputs twice => bitwise identical loss and gradients."""
+    g = Golden('vae_odd_padded')
+    runs = []
+    for _ in range(2):
+        vae, dec_loss, mu, logvar, total, kl = _run_gpu_vae(g)
+        grads = {k: p.grad.clone() for k, p in vae.named_parameters()
+                 if p.grad is not None}
+        runs.append((total.clone(), grads))
+    assert torch.equal(runs[0][0], runs[1][0])
+    for key in runs[0][1]:
+        assert torch.equal(runs[0][1][key], runs[1][1][key]), key
+
+
+def _cpu_dropout_masks(seed, steps, n_layers, batch, hid, p):
+    """numpy restatement of pcm_dropout_scale (csrc/common.h)."""
+    def mix(x):
+        x = (x + np.uint64(0x9E3779B97F4A7C15))
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+    masks = []
+    b = np.arange(batch, dtype=np.uint64).reshape(-1, 1)
+    j = np.arange(hid, dtype=np.uint64).reshape(1, -1)
+    with np.errstate(over='ignore'):
+        for t in range(steps):
+            per_layer = []
+            for layer in range(1, n_layers):
+                ctr = (np.uint64(layer) << np.uint64(56)) ^ \
+                    (np.uint64(t) << np.uint64(40)) ^ (b << np.uint64(16)) ^ j
+                h = mix(np.uint64(seed) ^ mix(ctr))
+                u = (h >> np.uint64(40)).astype(np.float32) * np.float32(
+                    1.0 / 16777216.0)
+                keep = (u >= np.float32(p)).astype(np.float32)
+                per_layer.append(
+                    torch.from_numpy(keep * np.float32(1.0 / (1.0 - p)))
+                )
+            masks.append(per_layer)
+    return masks
+
+
+def test_dropout_forward_backward_matches_oracle():
+    """Inter-layer GRU dropout (stack_rnn.py:104): the device mask is a pure
+    function of (seed, layer, t, b, j); regenerate it on the CPU, feed it to
+    the oracle and compare outputs and gradients (forward and backward must
+    use the same mask)."""
+    import paccmann_chemistry_amd as P
+    p = {
+        'latent_dim': 16, 'rnn_cell_size': 48, 'embedding_size': 12,
+        'vocab_size': 20, 'stack_width': 6, 'stack_depth': 5, 'n_layers': 3,
+        'dropout': 0.3, 'batch_size': 6, 'batch_mode': 'padded',
+        'embedding': 'learned', 'use_stack': True, 'bidirectional': False
+    }
+    steps, seed = 7, 123456789
+    sd = W.make_state_dict(p, 77)
+    enc_sd = O.sub_params(sd, 'encoder')
+    enc = P.StackGRUEncoder(p)
+    enc.load_state_dict(enc_sd)
+    enc = enc.to(_dev()).train()
+    tokens = W.synthetic_tokens(steps, 6, 20, 78)
+    out, h_final, _ = enc._run_sequence(
+        tokens.to(_dev()), None, None, None, seed=seed
+    )
+    weight = torch.linspace(-1, 1, out.numel()).view(out.shape)
+    (out * weight.to(_dev())).sum().backward()
+
+    ref = {k: v.clone().requires_grad_(k != 'embedding.weight' or True)
+           for k, v in enc_sd.items()}
+    masks = _cpu_dropout_masks(seed, steps, 3, 6, 48, 0.3)
+    hidden = torch.zeros(3, 6, 48)
+    stack = torch.zeros(6, 5, 6)
+    ref_out, ref_h, _ = O.stackgru_sequence(
+        ref, tokens, hidden, stack, None, True, masks
+    )
+    (ref_out * weight).sum().backward()
+    assert _rel_to_max(out, ref_out) < 1e-5
+    assert _rel_to_max(h_final, ref_h) < 1e-5
+    frac = np.mean([m.eq(0).float().mean().item() for row in masks for m in row])
+    assert 0.2 < frac < 0.4
+    named = dict(enc.named_parameters())
+    for key, val in ref.items():
+        if val.grad is None or key.startswith('hidden_to'):
+            continue
+        err = _rel_to_max(named[key].grad, val.grad)
+        assert err < GRAD_TOL, (key, err)
+
+
+def test_batch_independence_on_device():
+    """Reference invariants (models/tests/test_vae.py:68-142): identical rows
+    encode identically, and independently of the batch size."""
+    import paccmann_chemistry_amd as P
+    p = {
+        'latent_dim': 128, 'rnn_cell_size': 32, 'embedding_size': 30,
+        'vocab_size': 55, 'stack_width': 50, 'stack_depth': 51,
+        'n_layers': 3, 'dropout': .7, 'batch_size': 128, 'bidirectional': True,
+        'batch_mode': 'padded', 'embedding': 'learned', 'use_stack': True
+    }
+    sd = W.make_state_dict(p, 5)
+    enc_sd = O.sub_params(sd, 'encoder')
+    sample = torch.tensor(np.concatenate([[2], np.arange(3, 53)]))
+    results = []
+    for batch in (1, 2, 4, 12, 55, 128):
+        q = dict(p, batch_size=batch)
+        enc = P.StackGRUEncoder(q)
+        enc.load_state_dict(enc_sd)
+        enc = enc.to(_dev()).eval()
+        toks = sample.view(-1, 1).repeat(1, batch).to(_dev())
+        with torch.no_grad():
+            mu, logvar = enc.encoder_train_step(toks)
+        mu = mu.cpu()
+        for row in mu:
+            assert np.allclose(row, mu[0], rtol=1e-5, atol=1e-7)
+        results.append(mu[0])
+    for other in results[1:]:
+        assert np.allclose(other, results[0], rtol=1e-5, atol=1e-6)
+    # and against the oracle
+    bw = O.sub_params(sd, 'encoder.backward_stackgru')
+    ref_mu, _ = O.encoder_forward(
+        enc_sd, sample.view(-1, 1), p['stack_depth'], None, True, None, bw
+    )
+    assert _rel_to_max(results[0], ref_mu[0]) < 1e-5
+
+
+def test_full_batch_rows_match_small_batch():
+    """BASELINE config 2 size (B=512, T=120): every row of the big batch must
+    equal the same sequence run in a small batch that the oracle checks."""
+    import paccmann_chemistry_amd as P
+    p = {
+        'latent_dim': 256, 'rnn_cell_size': 512, 'embedding_size': 60,
+        'vocab_size': 60, 'stack_width': 50, 'stack_depth': 50, 'n_layers': 2,
+        'dropout': 0.0, 'batch_size': 512, 'batch_mode': 'padded',
+        'embedding': 'one_hot', 'use_stack': True, 'bidirectional': False
+    }
+    sd = W.make_state_dict(p, 300)
+    tokens = W.synthetic_tokens(120, 512, 60, 9)
+    targets = W.shifted_targets(tokens)
+    vae = _build_vae(p, sd, train=False)
+    with torch.no_grad():
+        mu, _ = vae.encode(tokens.to(_dev()))
+        loss = vae.decode(mu.unsqueeze(0), tokens.to(_dev()),
+                          targets.to(_dev()))
+    logits_big = vae.decoder.logits.cpu()
+    rows = [0, 101, 317, 511]
+    small = _build_vae(dict(p, batch_size=len(rows)), sd, train=False)
+    with torch.no_grad():
+        mu_s, _ = small.encode(tokens[:, rows].to(_dev()))
+        small.decode(mu_s.unsqueeze(0), tokens[:, rows].to(_dev()),
+                     targets[:, rows].to(_dev()))
+    assert _rel_to_max(mu.cpu()[rows], mu_s) < 1e-5
+    assert _rel_to_max(logits_big[:, rows], small.decoder.logits) < 1e-5
+    # oracle on the small batch
+    enc_sd, dec_sd = O.sub_params(sd, 'encoder'), O.sub_params(sd, 'decoder')
+    ref_mu, _ = O.encoder_forward(enc_sd, tokens[:, rows], 50)
+    _, ref_logits, _ = O.decoder_forward(
+        dec_sd, ref_mu, tokens[:, rows], targets[:, rows], 50
+    )
+    assert _rel_to_max(mu_s, ref_mu) < 1e-4
+    assert _rel_to_max(small.decoder.logits, ref_logits) < LOGIT_TOL
+    assert torch.isfinite(loss).item()
+
+
+def test_sampling_search_distribution():
+    """SamplingSearch.step (search.py:124-141): device draws follow
+    softmax(logits / T); checked through generation statistics."""
+    import paccmann_chemistry_amd as P
+    p = {
+        'latent_dim': 8, 'rnn_cell_size': 32, 'embedding_size': 12,
+        'vocab_size': 12, 'stack_width': 5, 'stack_depth': 4, 'n_layers': 1,
+        'dropout': 0.0, 'batch_size': 4096, 'batch_mode': 'padded',
+        'embedding': 'one_hot', 'use_stack': True
+    }
+    sd = W.make_state_dict(p, 12, scale=0.5)
+    vae = _build_vae(p, sd, train=False)
+    z = torch.zeros(1, 4096, 8, device=_dev())  # identical rows
+    tokens, logits = vae.decoder.generate_from_latent(
+        z, torch.tensor([2]), torch.tensor([3]),
+        search=P.SamplingSearch(temperature=0.7), generate_len=1, seed=99,
+        return_logits=True
+    )
+    probs = torch.softmax(logits[0, 0].cpu().double() / 0.7, 0)
+    counts = torch.bincount(tokens[:, 1].cpu(), minlength=12).double()
+    freq = counts / counts.sum()
+    assert (freq - probs).abs().max().item() < 0.03
+    again, _ = vae.decoder.generate_from_latent(
+        z, torch.tensor([2]), torch.tensor([3]),
+        search=P.SamplingSearch(temperature=0.7), generate_len=1, seed=99,
+        return_logits=True
+    )
+    assert torch.equal(tokens, again)
+
+
+def test_bad_token_raises():
+    """Out-of-vocabulary ids surface as RuntimeError
+    (generate_latent_codes.py:126 depends on it)."""
+    g = Golden('vae_tiny_padded_onehot')
+    vae = _build_vae(dict(g.params), g.weights, train=False)
+    toks = g.tensor('tokens').clone()
+    toks[2, 1] = 999
+    with torch.no_grad():
+        vae.encode(toks.to(_dev()))
+    with pytest.raises(RuntimeError):
+        vae.check_tokens()
+
+
+def test_cpu_tensor_fails_loudly():
+    from paccmann_chemistry_amd._lib import PaccmannHipError
+    g = Golden('vae_tiny_padded_onehot')
+    import paccmann_chemistry_amd as P
+    enc = P.StackGRUEncoder(dict(g.params))
+    with pytest.raises(PaccmannHipError):
+        enc.cpu().encoder_train_step(g.tensor('tokens'))
