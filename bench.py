@@ -1,0 +1,227 @@
+"""Headline benchmark: SMILES tokens/s of one training step (forward +
+backward + Adam) of the stack-augmented GRU VAE on synthetic SMILES-shaped
+batches -- BASELINE.json configs[1]: batch 512 per GPU, seq len 120, vocab 60
+(one-hot), H=512, L=2, stack 50x50, latent 256, fp32.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see the field notes in DESIGN.md section
+"Measurement").  `roofline` is for the dominant kernel (the fused GRU cell of
+the forward recurrence), its duration measured live with HIP events on the
+launch stream during the timed steps; `cpu_baseline` times the CPU oracle
+(oracle/stackgru_oracle.py, kind "port") on a bounded sample on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PARAMS = {
+    'latent_dim': 256, 'rnn_cell_size': 512, 'embedding_size': 60,
+    'vocab_size': 60, 'stack_width': 50, 'stack_depth': 50, 'n_layers': 2,
+    'dropout': 0.2, 'batch_size': 512, 'batch_mode': 'padded',
+    'embedding': 'one_hot', 'use_stack': True, 'bidirectional': False
+}
+SEQ_LEN = 120
+LR = 5e-4
+KL_GROWTH = 0.003
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, dense fp32 matrix peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=PARAMS['batch_size'],
+                    help='sequences per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=128)
+    ap.add_argument('--probe', type=int, default=1,
+                    help='kernel id for the roofline probe (1 = fused cell)')
+    return ap.parse_args()
+
+
+def cell_flops_per_launch(p, batch):
+    """Algorithmic FLOPs of one fused-cell launch, averaged over the layers
+    (2*3H*(W+H) layer 0, 2*3H*2H further layers, per
+    sequence-step; the one-hot token part is a gather, 0 FLOP)."""
+    hid, width, layers = p['rnn_cell_size'], p['stack_width'], p['n_layers']
+    per_seq = [2 * 3 * hid * (width + hid)] + \
+        [2 * 3 * hid * 2 * hid] * (layers - 1)
+    return batch * sum(per_seq) / layers
+
+
+def cpu_baseline(p, cpu_batch):
+    """The oracle (CPU restatement of the reference, torch CPU kernels +
+    autograd + torch.optim.Adam as training.py:132-156) on a bounded sample."""
+    from oracle import stackgru_oracle as O
+    from oracle import weights as W
+    threads = torch.get_num_threads()
+    q = dict(p, batch_size=cpu_batch, dropout=0.0)
+    sd = W.make_state_dict(q, 1234)
+    sd = {k: v.clone().requires_grad_('embedding' not in k)
+          for k, v in sd.items()}
+    opt = torch.optim.Adam([v for v in sd.values() if v.requires_grad], lr=LR)
+    tokens = W.synthetic_tokens(SEQ_LEN, cpu_batch, q['vocab_size'], 99)
+    targets = W.shifted_targets(tokens)
+    gen = torch.Generator().manual_seed(7)
+    times = []
+    for it in range(3):
+        eps = torch.randn(cpu_batch, q['latent_dim'], generator=gen)
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        dec_loss, mu, logvar, _, _ = O.vae_forward(
+            sd, tokens, tokens, targets, eps, q['stack_depth']
+        )
+        loss, _ = O.vae_loss(dec_loss, mu, logvar, KL_GROWTH, step=it)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {
+        'value': cpu_batch * SEQ_LEN / best,
+        'unit': 'tokens/s',
+        'cores': threads,
+        'kind': 'port',
+        'sample': f'oracle train step (fwd+bwd+Adam), batch {cpu_batch} x '
+                  f'seq {SEQ_LEN}, 1 warm-up + best of 2 timed steps, '
+                  f'{threads} torch threads',
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device(
+            'cuda', local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    import paccmann_chemistry_amd as P
+    from paccmann_chemistry_amd import _lib, dp
+    from paccmann_chemistry_amd.ops import KLDivFn
+    from paccmann_chemistry_amd.utils import kl_weight
+    from oracle import weights as W  # synthetic inputs only
+
+    p = dict(PARAMS, batch_size=args.batch)
+    torch.manual_seed(1234)
+    vae = P.TeacherVAE(P.StackGRUEncoder(p), P.StackGRUDecoder(p)).to(dev)
+    vae.train()
+    # identical random-init weights on every rank (seeded above)
+    tokens = W.synthetic_tokens(SEQ_LEN, args.batch, p['vocab_size'],
+                                1234 + rank).to(dev)
+    targets = W.shifted_targets(tokens)
+    # decoder input with whole-row word dropout (utils/utils.py:65-75)
+    g = torch.Generator().manual_seed(4321 + rank)
+    keep = torch.bernoulli(torch.full((SEQ_LEN, ), 0.85), generator=g)
+    dec_tokens = tokens.clone()
+    dec_tokens[(keep == 0).to(dev)] = 1
+
+    buckets = dp.GradientBuckets(vae, overlap=world > 1)
+    params = [q for q in vae.parameters() if q.requires_grad]
+    optimizer = torch.optim.Adam(params, lr=LR)
+    lib = _lib.load()
+
+    def step(global_step):
+        buckets.zero_grad()
+        dec_loss, mu, logvar = vae(tokens, dec_tokens, targets)
+        kl = KLDivFn.apply(mu, logvar)
+        kl_w = kl_weight(global_step, KL_GROWTH)
+        loss = dp.scale_losses(dec_loss, kl, kl_w)
+        loss.backward()
+        buckets.finish()
+        optimizer.step()
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    cells_per_step = 2 * SEQ_LEN * p['n_layers']
+    if args.probe:
+        _lib.check(lib.pcm_probe_enable(
+            args.probe, cells_per_step * args.steps * 2 + 16), 'probe')
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    vae.check_tokens()
+    probe_ms, probe_n, dropped = (ctypes.c_double(), ctypes.c_int64(),
+                                  ctypes.c_int64())
+    if args.probe:
+        lib.pcm_probe_read(ctypes.byref(probe_ms), ctypes.byref(probe_n),
+                           ctypes.byref(dropped))
+        lib.pcm_probe_enable(0, 0)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    final_loss = float(loss.item())
+    assert final_loss == final_loss, 'loss is NaN'
+
+    if rank == 0:
+        tokens_per_step = world * args.batch * SEQ_LEN
+        value = tokens_per_step * args.steps / elapsed
+        roofline = None
+        if args.probe == 1 and probe_n.value > 0:
+            avg_s = probe_ms.value / probe_n.value * 1e-3
+            achieved = cell_flops_per_launch(p, args.batch) / avg_s / 1e12
+            roofline = {
+                'bound': 'mfma', 'kernel': 'gru_cell_fwd_kernel',
+                'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
+                'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+                'traffic': None,
+                'avg_launch_us': avg_s * 1e6, 'launches': probe_n.value,
+            }
+        cpu = None
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline(p, args.cpu_batch)
+        line = {
+            'metric': 'SMILES tokens/sec (train fwd+bwd)',
+            'value': value, 'unit': 'tokens/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': 'Stack-GRU VAE training step (fwd+bwd+Adam), '
+                            f'batch {args.batch}/GPU, seq len {SEQ_LEN}, '
+                            'vocab 60 one-hot, H=512, L=2, stack 50x50, '
+                            'latent 256, dropout 0.2, padded mode',
+                'global_batch': world * args.batch, 'seq_len': SEQ_LEN,
+                'parallelism': f'dp{world}',
+            },
+            'roofline': roofline, 'cpu_baseline': cpu,
+            'final_loss': final_loss,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -76,6 +76,18 @@ const char *pcm_last_error(void);
 /* 0 if a gfx950 device is current and usable, PCM_EDEVICE otherwise. */
 int pcm_device_check(void);
 
+/*
+ * Measurement aid (no counterpart in the reference): while enabled for one
+ * kernel id, each launch of that kernel inside the recurrence is bracketed by
+ * hipEvents on its own stream.  pcm_probe_read synchronises on the recorded
+ * events and returns the summed duration and launch count since enable.
+ * Ids: 1 fused GRU cell (forward), 2 stack step (forward), 3 gate gradient,
+ * 4 stack step (backward), 5 per-step dgates.W GEMM group (backward, includes
+ * its split-K reduce); 0 disables.  Not thread safe; one device per process.
+ */
+int pcm_probe_enable(int32_t kernel_id, int32_t max_launches);
+int pcm_probe_read(double *total_ms, int64_t *launches, int64_t *dropped);
+
 /* StackGRU over a whole sequence ------------------------------------------*/
 
 /*

@@ -51,6 +51,13 @@ PROTOTYPES = {
     'pcm_version': (ctypes.c_int, []),
     'pcm_last_error': (ctypes.c_char_p, []),
     'pcm_device_check': (ctypes.c_int, []),
+    'pcm_probe_enable': (ctypes.c_int, [_I32, _I32]),
+    'pcm_probe_read': (
+        ctypes.c_int, [
+            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64),
+            ctypes.POINTER(_I64)
+        ]
+    ),
     'pcm_stackgru_saved_bytes': (_SZ, [_DIMS_P, _I32, _I32]),
     'pcm_stackgru_out_view': (
         ctypes.c_int,

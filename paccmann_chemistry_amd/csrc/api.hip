@@ -35,6 +35,42 @@ int pcm_check_launch(const char *what) {
     return PCM_OK;
 }
 
+// ---- launch-duration probe ----------------------------------------------------------
+#include <vector>
+int g_pcm_probe_id = 0;
+static std::vector<hipEvent_t> g_probe_ev;   // pairs: begin, end
+static size_t g_probe_used = 0;              // events handed out
+static size_t g_probe_cap = 0;
+static double g_probe_ms = 0.0;
+static long long g_probe_n = 0;
+static long long g_probe_dropped = 0;
+
+static void probe_drain() {
+    for (size_t i = 0; i + 1 < g_probe_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_probe_ev[i + 1]) == hipSuccess &&
+            hipEventElapsedTime(&ms, g_probe_ev[i], g_probe_ev[i + 1]) ==
+                hipSuccess) {
+            g_probe_ms += ms;
+            g_probe_n += 1;
+        }
+    }
+    g_probe_used = 0;
+}
+
+void pcm_probe_begin_(int id, hipStream_t st) {
+    (void)id;
+    if (g_probe_used + 2 > g_probe_cap) { g_probe_dropped++; return; }
+    (void)hipEventRecord(g_probe_ev[g_probe_used], st);
+}
+
+void pcm_probe_end_(int id, hipStream_t st) {
+    (void)id;
+    if (g_probe_used + 2 > g_probe_cap) return;
+    (void)hipEventRecord(g_probe_ev[g_probe_used + 1], st);
+    g_probe_used += 2;
+}
+
 // ---- layouts ----------------------------------------------------------------------
 static size_t take(size_t &off, size_t n) {
     size_t at = off;
@@ -145,7 +181,9 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         s.av = sb.av; s.xtop = sb.xtop; s.lengths = lengths;
         s.B = lay.B; s.H = lay.H; s.Hp = lay.Hp; s.D = lay.D; s.W = lay.W;
         s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
+        pcm_probe_begin(PCM_K_STACK_FWD, st);
         int rc = pcm_launch_stack_fwd(s, st);
+        pcm_probe_end(PCM_K_STACK_FWD, st);
         if (rc) return rc;
     }
     for (int l = 0; l < lay.L; ++l) {
@@ -166,7 +204,9 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         c.t = t; c.next_layer = l + 1;
         c.drop_p = drop_p; c.inv_keep = drop_p < 1.f ? 1.f / (1.f - drop_p) : 0.f;
         c.seed = seed;
+        pcm_probe_begin(PCM_K_CELL_FWD, st);
         int rc = pcm_launch_cell_fwd(c, st);
+        pcm_probe_end(PCM_K_CELL_FWD, st);
         if (rc) return rc;
     }
     return PCM_OK;
@@ -218,6 +258,34 @@ static int check_params(const SGLayout &lay, const pcm_stackgru_params *w,
 extern "C" {
 
 int pcm_version(void) { return 1; }
+
+int pcm_probe_enable(int32_t kernel_id, int32_t max_launches) {
+    PCM_REQUIRE(kernel_id >= 0 && kernel_id <= PCM_K_GEMM, PCM_EINVAL,
+                "probe: unknown kernel id %d", kernel_id);
+    probe_drain();
+    g_probe_ms = 0.0; g_probe_n = 0; g_probe_dropped = 0;
+    if (kernel_id != 0) {
+        const size_t want = (size_t)(max_launches > 0 ? max_launches : 0) * 2;
+        while (g_probe_ev.size() < want) {
+            hipEvent_t ev;
+            hipError_t e = hipEventCreate(&ev);
+            PCM_REQUIRE(e == hipSuccess, PCM_EDEVICE, "probe: %s",
+                        hipGetErrorString(e));
+            g_probe_ev.push_back(ev);
+        }
+        g_probe_cap = want;
+    }
+    g_pcm_probe_id = kernel_id;
+    return PCM_OK;
+}
+
+int pcm_probe_read(double *total_ms, int64_t *launches, int64_t *dropped) {
+    probe_drain();
+    if (total_ms) *total_ms = g_probe_ms;
+    if (launches) *launches = g_probe_n;
+    if (dropped) *dropped = g_probe_dropped;
+    return PCM_OK;
+}
 
 const char *pcm_last_error(void) { return g_err; }
 
@@ -411,7 +479,9 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             g.gates = gates;
             g.hprev = sv + lay.off_hs[l] + (size_t)t * lay.hs_step();
             g.lengths = lengths; g.B = B; g.H = H; g.Hp = Hp; g.t = t;
+            pcm_probe_begin(PCM_K_GATE_BWD, st);
             pcm_launch_gate_bwd(g, st);
+            pcm_probe_end(PCM_K_GATE_BWD, st);
 
             // dh[l] += dGh . W_hh  (dGh = cols [0,2H) and [3H,4H) of gates)
             GemmBatch gb;
@@ -441,7 +511,9 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                                             dtop, lay.Wp, B, lay.W, 3 * H);
                 gb.p[gb.count++] = p2;
             }
+            pcm_probe_begin(PCM_K_GEMM, st);
             rc = pcm_gemm_launch(gb, gs, gsb, st);
+            pcm_probe_end(PCM_K_GEMM, st);
             if (rc) return rc;
             if (!seg_ok) {
                 GemmBatch g2;
@@ -469,7 +541,9 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             s.lengths = lengths;
             s.B = B; s.H = H; s.Hp = Hp; s.D = lay.D; s.W = lay.W;
             s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
+            pcm_probe_begin(PCM_K_STACK_BWD, st);
             pcm_launch_stack_bwd(s, st);
+            pcm_probe_end(PCM_K_STACK_BWD, st);
             cur ^= 1;
         }
     }

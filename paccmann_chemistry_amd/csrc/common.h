@@ -75,6 +75,24 @@ int pcm_colsum_launch(const float *X, long long ldx, int M, int N, float *out,
                       const float *alpha_ptr, int accumulate, void *scratch,
                       size_t scratch_bytes, hipStream_t stream);
 
+// ---- launch-duration probe (bench.py roofline) ---------------------------------
+// When enabled for one kernel id, every launch of that kernel is bracketed by
+// hipEvents on its stream; pcm_probe_read() sums the elapsed times.
+#define PCM_K_CELL_FWD 1
+#define PCM_K_STACK_FWD 2
+#define PCM_K_GATE_BWD 3
+#define PCM_K_STACK_BWD 4
+#define PCM_K_GEMM 5
+extern int g_pcm_probe_id;
+void pcm_probe_begin_(int id, hipStream_t st);
+void pcm_probe_end_(int id, hipStream_t st);
+static inline void pcm_probe_begin(int id, hipStream_t st) {
+    if (g_pcm_probe_id == id) pcm_probe_begin_(id, st);
+}
+static inline void pcm_probe_end(int id, hipStream_t st) {
+    if (g_pcm_probe_id == id) pcm_probe_end_(id, st);
+}
+
 // ---- device helpers -------------------------------------------------------------
 __device__ __forceinline__ float pcm_sigmoid(float x) {
     return 1.0f / (1.0f + expf(-x));
