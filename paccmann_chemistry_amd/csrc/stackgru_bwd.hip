@@ -43,99 +43,162 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(GateBwdArgs a) {
     }
 }
 
-// One wave per batch row, 4 rows per block.
-constexpr int BROWS = 4;
+// One block of 512 threads per BROWS batch rows.  S_{t-1} and dL/dS'_t of the
+// rows are staged in LDS (one HBM read each), the three control-gradient sums
+// are block-reduced, and the block finishes with dL/dh_top += dc.Wc + du.Ws.
+constexpr int BROWS = 2;
+constexpr int BTHREADS = 512;
 
-__global__ __launch_bounds__(256) void stack_bwd_kernel(StackBwdArgs a) {
-    extern __shared__ float sm[];
-    // per row: dcu[AVW] (dc0..2, du[W]); a_v[AVW]
-    float *dcu = sm;                       // [BROWS][AVW]
-    float *avs = sm + BROWS * a.AVW;       // [BROWS][AVW]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x * BROWS + wave;
+__global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     const int W = a.W, D = a.D, DW = D * W, H = a.H;
-    const bool valid = b < a.B;
-    const bool frozen = valid && a.lengths && a.t >= a.lengths[b];
+    const int DWp = (DW + 3) & ~3;
+    float *Srow = sm;                       // [BROWS][DWp]  S_{t-1}
+    float *Grow = Srow + BROWS * DWp;       // [BROWS][DWp]  dL/dS'_t (+ dtop)
+    float *avs = Grow + BROWS * DWp;        // [BROWS][AVW]  a, v
+    float *dcu = avs + BROWS * a.AVW;       // [BROWS][AVW]  dc, du
+    float *red = dcu + BROWS * a.AVW;       // [BROWS][3][8] wave partials
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b0 = blockIdx.x * BROWS;
 
-    if (valid) {
-        for (int o = lane; o < a.AVW; o += 64)
-            avs[wave * a.AVW + o] = a.av[(long long)b * a.AVW + o];
+    if ((DW & 3) == 0) {
+        const int nq = DW >> 2;
+        for (int idx = tid; idx < BROWS * nq; idx += BTHREADS) {
+            const int r = idx / nq, q = idx - r * nq;
+            const int b = b0 + r;
+            f32x4 sv = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
+            if (b < a.B) {
+                sv = *(const f32x4 *)(a.S_prev + (long long)b * DW + q * 4);
+                if (a.dS_next)
+                    gv = *(const f32x4 *)(a.dS_next + (long long)b * DW + q * 4);
+            }
+            *(f32x4 *)(Srow + r * DWp + q * 4) = sv;
+            *(f32x4 *)(Grow + r * DWp + q * 4) = gv;
+        }
+    } else {
+        for (int idx = tid; idx < BROWS * DW; idx += BTHREADS) {
+            const int r = idx / DW, e = idx - r * DW;
+            const int b = b0 + r;
+            const bool ok = b < a.B;
+            Srow[r * DWp + e] = ok ? a.S_prev[(long long)b * DW + e] : 0.f;
+            Grow[r * DWp + e] =
+                (ok && a.dS_next) ? a.dS_next[(long long)b * DW + e] : 0.f;
+        }
+    }
+    for (int idx = tid; idx < BROWS * a.AVW; idx += BTHREADS) {
+        const int r = idx / a.AVW, o = idx - r * a.AVW;
+        const int b = b0 + r;
+        avs[idx] = b < a.B ? a.av[(long long)b * a.AVW + o] : 0.f;
     }
     __syncthreads();
-    if (valid) {
-        const float *Sp = a.S_prev + (long long)b * DW;
-        const float *Gn = a.dS_next ? a.dS_next + (long long)b * DW : nullptr;
-        const float *dtop = a.dtop + (long long)b * a.Wp;
-        float *dSp = a.dS_prev + (long long)b * DW;
-        const float *c = avs + wave * a.AVW;
+    // the stack top fed layer 0: its gradient joins row 0 of G
+    for (int idx = tid; idx < BROWS * W; idx += BTHREADS) {
+        const int r = idx / W, w = idx - r * W;
+        const int b = b0 + r;
+        if (b < a.B && !(a.lengths && a.t >= a.lengths[b]))
+            Grow[r * DWp + w] += a.dtop[(long long)b * a.Wp + w];
+    }
+    __syncthreads();
+
+    // elementwise adjoint + partial sums of the control gradients
+    float s_push[BROWS], s_pop[BROWS], s_noop[BROWS];
+#pragma unroll
+    for (int r = 0; r < BROWS; ++r) { s_push[r] = 0.f; s_pop[r] = 0.f; s_noop[r] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < BROWS; ++r) {
+        const int b = b0 + r;
+        if (b >= a.B) continue;
+        const bool frozen = a.lengths && a.t >= a.lengths[b];
+        const float *Sp = Srow + r * DWp;
+        const float *G = Grow + r * DWp;
+        const float *c = avs + r * a.AVW;
         const float a0 = c[0], a1 = c[1], a2 = c[2];
-        if (frozen) {
-            for (int e = lane; e < DW; e += 64) dSp[e] = Gn ? Gn[e] : 0.f;
-            for (int o = lane; o < a.AVW; o += 64) {
-                dcu[wave * a.AVW + o] = 0.f;
-                a.av[(long long)b * a.AVW + o] = 0.f;
-            }
-        } else {
-            // G = dL/dS'_t with the stack-top gradient added to row 0
-            float s_push = 0.f, s_pop = 0.f, s_noop = 0.f;
-            for (int e = lane; e < DW; e += 64) {
-                const int d = e / W, w = e - d * W;
-                const float g = (Gn ? Gn[e] : 0.f) + (d == 0 ? dtop[w] : 0.f);
-                const float s = Sp[e];
-                const float up = d == 0 ? c[3 + w] : Sp[e - W];
-                const float dn = d == D - 1 ? 0.f : Sp[e + W];
-                s_push = fmaf(g, up, s_push);
-                s_pop = fmaf(g, dn, s_pop);
-                s_noop = fmaf(g, s, s_noop);
-                // adjoint of the shifts: S[d] feeds S'[d] (no-op), S'[d+1]
-                // (push) and S'[d-1] (pop)
-                float v = a2 * g;
-                if (d + 1 < D) v += a0 * (Gn ? Gn[e + W] : 0.f);
-                if (d >= 1)
-                    v += a1 * ((Gn ? Gn[e - W] : 0.f) +
-                               (d == 1 ? dtop[w] : 0.f));
-                dSp[e] = v;
-            }
+        float *dSp = a.dS_prev + (long long)b * DW;
+        for (int e = tid; e < DW; e += BTHREADS) {
+            const float g = G[e];
+            if (frozen) { dSp[e] = g; continue; }
+            const int d = e / W, w = e - d * W;
+            const float s = Sp[e];
+            const float up = d == 0 ? c[3 + w] : Sp[e - W];
+            const float dn = d == D - 1 ? 0.f : Sp[e + W];
+            s_push[r] = fmaf(g, up, s_push[r]);
+            s_pop[r] = fmaf(g, dn, s_pop[r]);
+            s_noop[r] = fmaf(g, s, s_noop[r]);
+            // S[d] feeds S'[d] (no-op), S'[d+1] (push) and S'[d-1] (pop)
+            float v = a2 * g;
+            if (d + 1 < D) v += a0 * G[e + W];
+            if (d >= 1) v += a1 * G[e - W];
+            dSp[e] = v;
+        }
+    }
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                s_push += __shfl_xor(s_push, off, 64);
-                s_pop += __shfl_xor(s_pop, off, 64);
-                s_noop += __shfl_xor(s_noop, off, 64);
-            }
-            // softmax backward: dc_i = a_i * (da_i - sum_j a_j da_j)
-            const float dot = a0 * s_push + a1 * s_pop + a2 * s_noop;
-            float *out = dcu + wave * a.AVW;
-            if (lane == 0) {
-                out[0] = a0 * (s_push - dot);
-                out[1] = a1 * (s_pop - dot);
-                out[2] = a2 * (s_noop - dot);
-            }
-            // dv[w] = a_push * G[0][w]; du = dv * (1 - v^2)
-            for (int w = lane; w < W; w += 64) {
-                const float g0 = (Gn ? Gn[w] : 0.f) + dtop[w];
-                const float v = c[3 + w];
-                out[3 + w] = a0 * g0 * (1.f - v * v);
-            }
-            for (int o = 3 + W + lane; o < a.AVW; o += 64) out[o] = 0.f;
+    for (int r = 0; r < BROWS; ++r) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s_push[r] += __shfl_xor(s_push[r], off, 64);
+            s_pop[r] += __shfl_xor(s_pop[r], off, 64);
+            s_noop[r] += __shfl_xor(s_noop[r], off, 64);
+        }
+        if (lane == 0) {
+            red[(r * 3 + 0) * 8 + wave] = s_push[r];
+            red[(r * 3 + 1) * 8 + wave] = s_pop[r];
+            red[(r * 3 + 2) * 8 + wave] = s_noop[r];
         }
     }
     __syncthreads();
-    if (valid && !frozen) {
-        float *out = dcu + wave * a.AVW;
-        // keep dc/du for the time-parallel dWc / dWs products
-        for (int o = lane; o < a.AVW; o += 64)
-            a.av[(long long)b * a.AVW + o] = out[o];
-        // dL/dh_top += dc.Wc + du.Ws
-        float *dh = a.dh_top + (long long)b * a.Hp;
-        for (int j = lane; j < H; j += 64) {
-            float s = 0.f;
-#pragma unroll
-            for (int o = 0; o < 3; ++o)
-                s = fmaf(out[o], a.ctrl_w[(long long)o * H + j], s);
-            for (int w = 0; w < W; ++w)
-                s = fmaf(out[3 + w], a.push_w[(long long)w * H + j], s);
-            dh[j] += s;
+    if (tid < BROWS) {
+        const int r = tid;
+        const int b = b0 + r;
+        const bool frozen = b < a.B && a.lengths && a.t >= a.lengths[b];
+        float sp = 0.f, so = 0.f, sn = 0.f;
+        for (int w8 = 0; w8 < 8; ++w8) {
+            sp += red[(r * 3 + 0) * 8 + w8];
+            so += red[(r * 3 + 1) * 8 + w8];
+            sn += red[(r * 3 + 2) * 8 + w8];
         }
+        const float *c = avs + r * a.AVW;
+        // softmax backward: dc_i = a_i * (da_i - sum_j a_j da_j)
+        const float dot = c[0] * sp + c[1] * so + c[2] * sn;
+        float *out = dcu + r * a.AVW;
+        out[0] = frozen ? 0.f : c[0] * (sp - dot);
+        out[1] = frozen ? 0.f : c[1] * (so - dot);
+        out[2] = frozen ? 0.f : c[2] * (sn - dot);
+    }
+    // dv[w] = a_push * G[0][w]; du = dv * (1 - v^2); zero the padding
+    for (int idx = tid; idx < BROWS * (a.AVW - 3); idx += BTHREADS) {
+        const int r = idx / (a.AVW - 3), w = idx - r * (a.AVW - 3);
+        const int b = b0 + r;
+        const bool frozen = b < a.B && a.lengths && a.t >= a.lengths[b];
+        float val = 0.f;
+        if (w < W && !frozen) {
+            const float *c = avs + r * a.AVW;
+            const float v = c[3 + w];
+            val = c[0] * Grow[r * DWp + w] * (1.f - v * v);
+        }
+        dcu[r * a.AVW + 3 + w] = val;
+    }
+    __syncthreads();
+    // keep dc/du for the time-parallel dWc / dWs products
+    for (int idx = tid; idx < BROWS * a.AVW; idx += BTHREADS) {
+        const int r = idx / a.AVW, o = idx - r * a.AVW;
+        const int b = b0 + r;
+        if (b < a.B) a.av[(long long)b * a.AVW + o] = dcu[idx];
+    }
+    // dL/dh_top += dc.Wc + du.Ws
+    for (int idx = tid; idx < BROWS * H; idx += BTHREADS) {
+        const int r = idx / H, j = idx - r * H;
+        const int b = b0 + r;
+        if (b >= a.B) continue;
+        if (a.lengths && a.t >= a.lengths[b]) continue;
+        const float *out = dcu + r * a.AVW;
+        float s = 0.f;
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+            s = fmaf(out[o], a.ctrl_w[(long long)o * H + j], s);
+#pragma unroll 10
+        for (int w = 0; w < W; ++w)
+            s = fmaf(out[3 + w], a.push_w[(long long)w * H + j], s);
+        a.dh_top[(long long)b * a.Hp + j] += s;
     }
 }
 
@@ -180,9 +243,14 @@ int pcm_launch_gate_bwd(const GateBwdArgs &a, hipStream_t stream) {
 }
 
 int pcm_launch_stack_bwd(const StackBwdArgs &a, hipStream_t stream) {
-    const size_t lds = (size_t)2 * BROWS * a.AVW * sizeof(float);
+    const int DWp = (a.D * a.W + 3) & ~3;
+    const size_t lds =
+        (size_t)BROWS * (2 * DWp + 2 * a.AVW + 3 * 8) * sizeof(float);
+    PCM_REQUIRE(lds <= 64 * 1024, PCM_EINVAL,
+                "stack step (backward): stack %dx%d exceeds the 64 KiB LDS "
+                "row cache", a.D, a.W);
     hipLaunchKernelGGL(stack_bwd_kernel, dim3((a.B + BROWS - 1) / BROWS),
-                       dim3(256), lds, stream, a);
+                       dim3(BTHREADS), lds, stream, a);
     return 0;
 }
 

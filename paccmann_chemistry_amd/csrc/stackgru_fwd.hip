@@ -188,46 +188,94 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_kernel(CellFwdArgs a) {
 // ------------------------------------------------------------------------------
 // stack controls + fused stack update
 // ------------------------------------------------------------------------------
-constexpr int SROWS = 4;  // batch rows per block
+// One block of 512 threads per SROWS batch rows.  The rows' previous stacks are
+// staged into LDS while the 3+W control / push dot products run (weights
+// stream from L2, 8 waves x 7 outputs, lanes along K), so the update itself
+// reads HBM once and writes once (20 KB / row, the algorithmic minimum).
+constexpr int SROWS = 2;
+constexpr int STHREADS = 512;
+constexpr int SOUT = 7;  // outputs per wave (8 waves x 7 = 56 >= 3 + W)
 
-__global__ __launch_bounds__(256) void stack_step_fwd_kernel(StackFwdArgs a) {
-    extern __shared__ float sm[];
-    float *hrow = sm;                         // [SROWS][H]
-    float *cu = sm + SROWS * a.H;             // [SROWS][AVW] pre-activations -> a, v
+__global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
+    StackFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int H = a.H, W = a.W, D = a.D, DW = D * W, NO = 3 + W;
+    const int DWp = (DW + 3) & ~3;
+    float *Srow = sm;                          // [SROWS][DWp]
+    float *hrow = Srow + SROWS * DWp;          // [SROWS][H]
+    float *cu = hrow + SROWS * H;              // [SROWS][AVW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * SROWS;
-    const int H = a.H, W = a.W, D = a.D, DW = D * W, NO = 3 + W;
 
-    for (int idx = tid; idx < SROWS * H; idx += 256) {
+    // stage previous stacks (vectorised when the row size allows it)
+    if ((DW & 3) == 0) {
+        const int nq = DW >> 2;
+        for (int idx = tid; idx < SROWS * nq; idx += STHREADS) {
+            const int r = idx / nq, q = idx - r * nq;
+            const int b = b0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b < a.B)
+                v = *(const f32x4 *)(a.S_prev + (long long)b * DW + q * 4);
+            *(f32x4 *)(Srow + r * DWp + q * 4) = v;
+        }
+    } else {
+        for (int idx = tid; idx < SROWS * DW; idx += STHREADS) {
+            const int r = idx / DW, e = idx - r * DW;
+            const int b = b0 + r;
+            Srow[r * DWp + e] = b < a.B ? a.S_prev[(long long)b * DW + e] : 0.f;
+        }
+    }
+    for (int idx = tid; idx < SROWS * H; idx += STHREADS) {
         const int r = idx / H, k = idx - r * H;
         const int b = b0 + r;
         hrow[idx] = b < a.B ? a.htop[(long long)b * a.Hp + k] : 0.f;
     }
     __syncthreads();
 
-    // dot products: wave handles outputs o = wave, wave+4, ...; lanes stride K
-    for (int o = wave; o < NO; o += 4) {
-        const float *wrow = o < 3 ? a.ctrl_w + (long long)o * H
-                                  : a.push_w + (long long)(o - 3) * H;
-        float p[SROWS];
+    // dot products: wave handles SOUT outputs per pass, lanes stride K
+    for (int obase = wave * SOUT; obase < NO; obase += 8 * SOUT) {
+        float p[SOUT][SROWS];
+        const float *wrow[SOUT];
 #pragma unroll
-        for (int r = 0; r < SROWS; ++r) p[r] = 0.f;
+        for (int i = 0; i < SOUT; ++i) {
+            const int o = min(obase + i, NO - 1);
+            wrow[i] = o < 3 ? a.ctrl_w + (long long)o * H
+                            : a.push_w + (long long)(o - 3) * H;
+#pragma unroll
+            for (int r = 0; r < SROWS; ++r) p[i][r] = 0.f;
+        }
+#pragma unroll 2
         for (int k = lane; k < H; k += 64) {
-            const float w = wrow[k];
+            float w[SOUT];
 #pragma unroll
-            for (int r = 0; r < SROWS; ++r) p[r] = fmaf(w, hrow[r * H + k], p[r]);
+            for (int i = 0; i < SOUT; ++i) w[i] = wrow[i][k];
+#pragma unroll
+            for (int r = 0; r < SROWS; ++r) {
+                const float hv = hrow[r * H + k];
+#pragma unroll
+                for (int i = 0; i < SOUT; ++i) p[i][r] = fmaf(w[i], hv, p[i][r]);
+            }
         }
 #pragma unroll
-        for (int r = 0; r < SROWS; ++r) {
-            float v = p[r];
+        for (int i = 0; i < SOUT; ++i)
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            p[r] = v;
-        }
+            for (int r = 0; r < SROWS; ++r) {
+                float v = p[i][r];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                p[i][r] = v;
+            }
         if (lane == 0) {
-            const float bias = o < 3 ? a.ctrl_b[o] : a.push_b[o - 3];
 #pragma unroll
-            for (int r = 0; r < SROWS; ++r) cu[r * a.AVW + o] = p[r] + bias;
+            for (int i = 0; i < SOUT; ++i) {
+                const int o = obase + i;
+                if (o < NO) {
+                    const float bias = o < 3 ? a.ctrl_b[o] : a.push_b[o - 3];
+#pragma unroll
+                    for (int r = 0; r < SROWS; ++r)
+                        cu[r * a.AVW + o] = p[i][r] + bias;
+                }
+            }
         }
     }
     __syncthreads();
@@ -240,24 +288,24 @@ __global__ __launch_bounds__(256) void stack_step_fwd_kernel(StackFwdArgs a) {
         const float s = e0 + e1 + e2;
         c[0] = e0 / s; c[1] = e1 / s; c[2] = e2 / s;
     }
-    for (int idx = tid; idx < SROWS * W; idx += 256) {
+    for (int idx = tid; idx < SROWS * W; idx += STHREADS) {
         const int r = idx / W, w = idx - r * W;
         cu[r * a.AVW + 3 + w] = tanhf(cu[r * a.AVW + 3 + w]);
     }
     __syncthreads();
 
     // record a, v (needed by the reverse pass) and update the stack
-    for (int idx = tid; idx < SROWS * a.AVW; idx += 256) {
+    for (int idx = tid; idx < SROWS * a.AVW; idx += STHREADS) {
         const int r = idx / a.AVW, o = idx - r * a.AVW;
         const int b = b0 + r;
         if (b < a.B) a.av[(long long)b * a.AVW + o] = o < NO ? cu[idx] : 0.f;
     }
-    for (int idx = tid; idx < SROWS * DW; idx += 256) {
+    for (int idx = tid; idx < SROWS * DW; idx += STHREADS) {
         const int r = idx / DW, e = idx - r * DW;
         const int b = b0 + r;
         if (b >= a.B) continue;
         const int d = e / W, w = e - d * W;
-        const float *Sp = a.S_prev + (long long)b * DW;
+        const float *Sp = Srow + r * DWp;
         const float s = Sp[e];
         float nv = s;
         if (!(a.lengths && a.t >= a.lengths[b])) {
@@ -272,7 +320,7 @@ __global__ __launch_bounds__(256) void stack_step_fwd_kernel(StackFwdArgs a) {
         if (d == 0) a.xtop[(long long)b * a.Wp + w] = nv;
     }
     const int padw = a.Wp - W;
-    for (int idx = tid; idx < SROWS * padw; idx += 256) {
+    for (int idx = tid; idx < SROWS * padw; idx += STHREADS) {
         const int r = idx / padw, w = W + idx - r * padw;
         const int b = b0 + r;
         if (b < a.B) a.xtop[(long long)b * a.Wp + w] = 0.f;
@@ -359,12 +407,14 @@ int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
 }
 
 int pcm_launch_stack_fwd(const StackFwdArgs &a, hipStream_t stream) {
-    const size_t lds = (size_t)SROWS * (a.H + a.AVW) * sizeof(float);
+    const int DWp = (a.D * a.W + 3) & ~3;
+    const size_t lds = (size_t)SROWS * (DWp + a.H + a.AVW) * sizeof(float);
     PCM_REQUIRE(lds <= 64 * 1024, PCM_EINVAL,
-                "stack step: hidden size %d too large for the LDS row cache",
-                a.H);
+                "stack step: stack %dx%d + hidden %d exceed the 64 KiB LDS "
+                "row cache", a.D, a.W, a.H);
     dim3 grid((a.B + SROWS - 1) / SROWS);
-    hipLaunchKernelGGL(stack_step_fwd_kernel, grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(stack_step_fwd_kernel, grid, dim3(STHREADS), lds, stream,
+                       a);
     return 0;
 }
 
