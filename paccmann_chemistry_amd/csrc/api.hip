@@ -148,6 +148,9 @@ int pcm_sg_scratch(const SGLayout &lay, SGScratch *o) {
     o->off_onehot = take(off, (size_t)lay.T * lay.B * lay.V);
     o->off_dtokg = take(off, (size_t)lay.V * 3 * lay.H);
     o->off_tmp = take(off, (size_t)lay.B * lay.Hp);
+    for (int l = 0; l < lay.L; ++l)
+        o->off_wpackT[l] =
+            take(off, (size_t)(lay.H + lay.Kxp[l]) * 3 * lay.H);
     o->off_gemm = take(off, GEMM_SCRATCH_FLOATS);
     o->gemm_bytes = GEMM_SCRATCH_FLOATS * sizeof(float);
     o->total = off;
@@ -465,6 +468,19 @@ int pcm_stackgru_backward(const pcm_dims *dims,
     }
     float *dtop = scf + sc.off_dtop;
     float *tmp = scf + sc.off_tmp;
+    // fused reverse cell needs whole 64-wide chunks inside every gate segment
+    const bool fused_bwd = (H % 64) == 0;
+    if (fused_bwd) {
+        for (int l = 0; l < L; ++l) {
+            PackTArgs pt;
+            pt.w_ih = weights->w_ih[l]; pt.w_hh = weights->w_hh[l];
+            pt.wpackT = scf + sc.off_wpackT[l];
+            pt.H = H; pt.Kx = lay.Kx[l]; pt.Kxp = lay.Kxp[l];
+            pt.ld_ih = l == 0 ? ld0 : H;
+            pt.x_off = l == 0 ? lay.E : 0;
+            pcm_launch_packT(pt, st);
+        }
+    }
 
     for (int t = T - 1; t >= 0; --t) {
         for (int l = L - 1; l >= 0; --l) {
@@ -483,6 +499,27 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             pcm_launch_gate_bwd(g, st);
             pcm_probe_end(PCM_K_GATE_BWD, st);
 
+            if (fused_bwd) {
+                CellBwdArgs cb;
+                cb.dgates = gates;
+                cb.wpackT = scf + sc.off_wpackT[l];
+                cb.dh = dhl;
+                cb.dx = l > 0 ? dh + (size_t)(l - 1) * B * Hp : dtop;
+                cb.ldx = l > 0 ? Hp : lay.Wp;
+                cb.dx_accumulate = l > 0 ? 1 : 0;
+                cb.dx_cols = l > 0 ? H : lay.Wp;
+                cb.B = B; cb.H = H; cb.Hp = Hp;
+                cb.NT = H + lay.Kxp[l];
+                cb.t = t; cb.layer = l;
+                cb.drop_p = (l > 0 && drop) ? dropout_p : 0.f;
+                cb.inv_keep = cb.drop_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
+                cb.seed = seed;
+                pcm_probe_begin(PCM_K_GEMM, st);
+                pcm_launch_cell_bwd(cb, st);
+                pcm_probe_end(PCM_K_GEMM, st);
+                continue;
+            }
+            // generic path (H not a multiple of 64):
             // dh[l] += dGh . W_hh  (dGh = cols [0,2H) and [3H,4H) of gates)
             GemmBatch gb;
             gb.count = 0;

@@ -48,6 +48,7 @@ struct SGScratch {
     size_t off_onehot;  // T*B x V  one-hot of the input tokens
     size_t off_dtokg;   // V x 3H   gradient of the token gate table
     size_t off_tmp;     // 3H x E   scratch product
+    size_t off_wpackT[PCM_MAX_LAYERS];  // (H + Kxp) x 3H transposed weights
     size_t off_gemm;    // split-K slabs / column-sum partials
     size_t gemm_bytes;
     size_t total;       // floats
@@ -112,6 +113,31 @@ struct GateBwdArgs {
     int B, H, Hp, t;
 };
 int pcm_launch_gate_bwd(const GateBwdArgs &a, hipStream_t stream);
+
+// Fused reverse GRU cell (H % 64 == 0): one launch computes
+//   dh[l]   += [dr,dz,dnh] . W_hh                (columns 0..H-1 of the tile grid)
+//   dx       = [dr,dz,dni] . W_ih[:, x-part]     (columns H.. ) which is added,
+//              dropout-masked, to dh[l-1] (l > 0) or stored as dtop (l == 0)
+// from K-contiguous transposed weights wpackT[(n), 3H].
+struct CellBwdArgs {
+    const float *dgates;  // [B, 4H]  dr, dz, dni, dnh
+    const float *wpackT;  // [H + Kxp, 3H]
+    float *dh;            // [B, Hp]  += (this layer)
+    float *dx;            // [B, ldx] += (l > 0: dh of the layer below) or = (dtop)
+    int ldx, dx_accumulate, dx_cols;
+    int B, H, Hp, NT;     // NT = H + Kxp rows of wpackT
+    int t, layer;
+    float drop_p, inv_keep;  // drop_p > 0: mask dx with the forward's dropout
+    uint64_t seed;
+};
+int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream);
+
+struct PackTArgs {
+    const float *w_ih, *w_hh;
+    float *wpackT;        // [H + Kxp, 3H]
+    int H, Kx, Kxp, ld_ih, x_off;
+};
+int pcm_launch_packT(const PackTArgs &a, hipStream_t stream);
 
 struct StackBwdArgs {
     const float *dS_next; // [B, D*W] dL/dS'_t (null = zeros)

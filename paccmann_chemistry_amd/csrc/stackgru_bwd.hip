@@ -202,6 +202,154 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------
+// fused reverse GRU cell: dgates . W on fp32 MFMA, LDS-staged 64-wide K chunks,
+// intra-block split-K over the 4 waves, accumulate / dropout-mask epilogue
+// ------------------------------------------------------------------------------
+constexpr int BCK = 64;         // K per chunk
+constexpr int BLDT = BCK + 4;   // LDS row stride (floats)
+constexpr int BCM = 32;         // batch rows per block
+constexpr int BCN = 64;         // output columns per block (2 MFMA tiles)
+constexpr int BA_TILE = BCM * BLDT;
+constexpr int BW_TILE = BCN * BLDT;
+constexpr int BCELL_LDS = 2 * (BA_TILE + BW_TILE);  // floats (52224 B)
+static_assert(BCELL_LDS >= 4 * 2 * 1024, "reduction buffer must fit");
+
+__global__ __launch_bounds__(256) void gru_cell_bwd_kernel(CellBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[BCELL_LDS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * BCN;   // first output column (row of wpackT)
+    const int b0 = blockIdx.y * BCM;
+    const int H = a.H, K3 = 3 * H;
+    const bool hidden_side = n0 < H;   // tile of dh[l] (uses dnh) or of dx (dni)
+    const int nchunks = K3 / BCK;
+
+    f32x4 ra[2], rw[4];
+    auto load_chunk = [&](int c) {
+        int kb = c * BCK;
+        // dgates columns: [0,2H) shared; third segment dni at 2H, dnh at 3H
+        const int acol = (kb >= 2 * H && hidden_side) ? kb + H : kb;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 4, q = idx & 15;
+            const int b = b0 + row;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (b < a.B)
+                v = *(const f32x4 *)(a.dgates + (long long)b * 4 * H + acol +
+                                     q * 4);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx >> 4, q = idx & 15;  // row 0..63
+            rw[i] = *(const f32x4 *)(a.wpackT + (long long)(n0 + row) * K3 + kb +
+                                     q * 4);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+        float *As = lds + buf * (BA_TILE + BW_TILE);
+        float *Ws = As + BA_TILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            *(f32x4 *)(As + (idx >> 4) * BLDT + (idx & 15) * 4) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            *(f32x4 *)(Ws + (idx >> 4) * BLDT + (idx & 15) * 4) = rw[i];
+        }
+    };
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    const int lrow = lane & 31, lh = lane >> 5;
+    load_chunk(0);
+    int buf = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        store_chunk(buf);
+        __syncthreads();
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        const float *As = lds + buf * (BA_TILE + BW_TILE);
+        const float *Ws = As + BA_TILE;
+        const int koff = wave * 16 + 4 * lh;
+        f32x4 fa[2], f0[2], f1[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            fa[s] = *(const f32x4 *)(As + lrow * BLDT + koff + 8 * s);
+            f0[s] = *(const f32x4 *)(Ws + lrow * BLDT + koff + 8 * s);
+            f1[s] = *(const f32x4 *)(Ws + (32 + lrow) * BLDT + koff + 8 * s);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][e], f0[s][e],
+                                                            acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][e], f1[s][e],
+                                                            acc1, 0, 0, 0);
+            }
+        buf ^= 1;
+    }
+
+    __syncthreads();
+    float *red = lds;  // [wave][tile][32][32]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float *base = red + (wave * 2) * 1024 + row * 32 + lrow;
+        base[0] = acc0[r];
+        base[1024] = acc1[r];
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int e = tid + 256 * q;       // 0..2047
+        const int tl = e >> 10, ee = e & 1023;
+        const int row = ee >> 5, col = ee & 31;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += red[(w * 2 + tl) * 1024 + ee];
+        const int b = b0 + row, n = n0 + tl * 32 + col;
+        if (b >= a.B) continue;
+        if (hidden_side) {
+            a.dh[(long long)b * a.Hp + n] += v;
+        } else {
+            const int j = n - H;
+            if (j >= a.dx_cols) continue;
+            if (a.drop_p > 0.f)
+                v *= pcm_dropout_scale(a.seed, a.layer, a.t, b, j, a.drop_p,
+                                       a.inv_keep);
+            float *dst = a.dx + (long long)b * a.ldx + j;
+            *dst = a.dx_accumulate ? *dst + v : v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void packT_kernel(PackTArgs a) {
+    // wpackT[n][k], k in [0,3H): n < H -> W_hh[k][n]; n >= H -> W_ih[k][x_off+n-H]
+    const int K3 = 3 * a.H;
+    const long long total = (long long)(a.H + a.Kxp) * K3;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * 256) {
+        // idx enumerates (k, n) with n fastest so the READS are coalesced
+        const int n = (int)(idx % (a.H + a.Kxp));
+        const int k = (int)(idx / (a.H + a.Kxp));
+        float v = 0.f;
+        if (n < a.H) v = a.w_hh[(long long)k * a.H + n];
+        else if (n - a.H < a.Kx)
+            v = a.w_ih[(long long)k * a.ld_ih + a.x_off + (n - a.H)];
+        a.wpackT[(long long)n * K3 + k] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void dropout_add_kernel(
     float *dst, long long ldd, const float *src, long long lds_, int B, int H,
     uint64_t seed, int layer, int t, float p, float inv_keep) {
@@ -238,6 +386,19 @@ int grid_for(long long n) {
 
 int pcm_launch_gate_bwd(const GateBwdArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for((long long)a.B * a.H)),
+                       dim3(256), 0, stream, a);
+    return 0;
+}
+
+int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream) {
+    dim3 grid(a.NT / BCN, (a.B + BCM - 1) / BCM);
+    hipLaunchKernelGGL(gru_cell_bwd_kernel, grid, dim3(256), 0, stream, a);
+    return 0;
+}
+
+int pcm_launch_packT(const PackTArgs &a, hipStream_t stream) {
+    hipLaunchKernelGGL(packT_kernel,
+                       dim3(grid_for((long long)(a.H + a.Kxp) * 3 * a.H)),
                        dim3(256), 0, stream, a);
     return 0;
 }
