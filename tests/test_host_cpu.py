@@ -1,0 +1,221 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol
+the header declares, and the host-side mirror keeps the reference's
+constructor / params schema / state_dict keys / error behaviour."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, 'include', 'paccmann_hip.h')
+
+
+def _declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(pcm_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from paccmann_chemistry_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), 'run __graft_entry__.build() first'
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(raw, name), f'{name} declared but not exported'
+    # the ctypes prototypes cover the header one to one
+    assert sorted(_lib.PROTOTYPES) == names
+    lib = _lib.load()
+    assert lib.pcm_version() == _lib.ABI_VERSION
+
+
+def test_size_helpers_without_gpu():
+    """Pure host arithmetic of the ABI (no device call)."""
+    from paccmann_chemistry_amd import _lib
+    lib = _lib.load()
+    dims = _lib.make_dims(512, 60, 60, 512, 2, 50, 50, True)
+    train = lib.pcm_stackgru_saved_bytes(ctypes.byref(dims), 120, 1)
+    infer = lib.pcm_stackgru_saved_bytes(ctypes.byref(dims), 120, 0)
+    assert train > infer > 0
+    # training keeps hidden states, 4H gates and the [D,W] stack of every step
+    floor = 120 * 512 * (2 * 512 + 2 * 4 * 512 + 2500) * 4
+    assert floor < train < 2 * floor
+    off, ld = ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.pcm_stackgru_out_view(
+        ctypes.byref(dims), 120, 1, ctypes.byref(off), ctypes.byref(ld)
+    ) == 0
+    assert ld.value == 512 and off.value > 0
+    bad = _lib.make_dims(0, 60, 60, 512, 2, 50, 50, True)
+    assert lib.pcm_stackgru_saved_bytes(ctypes.byref(bad), 120, 1) == 0
+    assert b'must be positive' in lib.pcm_last_error()
+    assert lib.pcm_kl_scratch_floats(131072) == 128
+
+
+PARAMS = {
+    'latent_dim': 16, 'rnn_cell_size': 32, 'embedding_size': 20,
+    'vocab_size': 20, 'stack_width': 5, 'stack_depth': 7, 'n_layers': 2,
+    'dropout': 0.1, 'batch_size': 4, 'batch_mode': 'padded',
+    'embedding': 'one_hot'
+}
+
+
+def test_state_dict_keys_match_reference_layout():
+    """The 34 keys listed in SURVEY.md section 8b (checkpoint interchange)."""
+    import paccmann_chemistry_amd as P
+    from oracle import weights as W
+    vae = P.TeacherVAE(P.StackGRUEncoder(PARAMS), P.StackGRUDecoder(PARAMS))
+    sd = vae.state_dict()
+    expected = W.vae_shapes(dict(PARAMS, use_stack=True))
+    assert len(sd) == 34
+    assert {k: tuple(v.shape) for k, v in sd.items()} == expected
+    # one-hot table is frozen and the identity (stack_rnn.py:88-97)
+    assert not vae.encoder.embedding.weight.requires_grad
+    assert torch.equal(vae.encoder.embedding.weight, torch.eye(20))
+    bi = P.StackGRUEncoder(dict(PARAMS, bidirectional=True))
+    assert any(k.startswith('backward_stackgru.') for k in bi.state_dict())
+    assert bi.hidden_to_mu.in_features == 64
+
+
+def test_same_default_init_as_reference_order():
+    """Same constructor order => same draws under the same torch seed as
+    nn.Linear / nn.Embedding / nn.GRU in the reference."""
+    import paccmann_chemistry_amd as P
+    p = dict(PARAMS, embedding='learned', embedding_size=12)
+    torch.manual_seed(11)
+    ours = P.StackGRU(p)
+    torch.manual_seed(11)
+    lin1 = torch.nn.Linear(32, 3)
+    lin2 = torch.nn.Linear(32, 5)
+    emb = torch.nn.Embedding(20, 12, padding_idx=0)
+    gru = torch.nn.GRU(17, 32, 2, dropout=0.1)
+    assert torch.equal(ours.stack_controls_layer.weight, lin1.weight)
+    assert torch.equal(ours.stack_input_layer.bias, lin2.bias)
+    assert torch.equal(ours.embedding.weight, emb.weight)
+    for name, param in gru.named_parameters():
+        assert torch.equal(getattr(ours.gru, name), param), name
+
+
+def test_error_behaviour():
+    import paccmann_chemistry_amd as P
+    with pytest.raises(TypeError):
+        P.StackGRU(dict(PARAMS, batch_mode=None))
+    with pytest.raises(NotImplementedError):
+        P.StackGRU(dict(PARAMS, batch_mode='ragged'))
+    enc = P.StackGRUEncoder(PARAMS)
+    packed = torch.nn.utils.rnn.pack_sequence([torch.tensor([2, 5, 3])])
+    with pytest.raises(TypeError):
+        enc._forward_pass_padded(packed, None, None)
+    with pytest.raises(TypeError):
+        enc._forward_pass_packed(torch.zeros(3, 4).long(), None, None)
+    with pytest.raises(ValueError):
+        enc._post_gru_reshape(torch.zeros(2, 5, 32))
+    hidden = torch.arange(32.).repeat(2, 4, 1)
+    assert torch.equal(enc._post_gru_reshape(hidden), hidden[-1])
+    dec = P.StackGRUDecoder(dict(PARAMS, batch_mode='Packed'))
+    with pytest.raises(TypeError):
+        dec._forward_pass_packed(torch.zeros(3, 4).long(), None, None, None)
+    vae = P.TeacherVAE(enc, dec)
+    with pytest.raises(TypeError):
+        vae._associate_language(object())
+
+
+def test_search_golden_tokens():
+    """The reference's golden vectors (utils/tests/test_search.py:7-122)."""
+    from paccmann_chemistry_amd.search import (
+        BeamSearch, GreedySearch, SamplingSearch
+    )
+    logits = torch.tensor(
+        [[[0.1, 0.2, 0.3, 0.4, 0.5], [0.5, 0.4, 0.3, 0.2, 0.1]] * 5] * 2
+    )
+    greedy = GreedySearch()
+    assert greedy(logits).tolist() == [[4, 0] * 5] * 2
+    for step_logits, token in zip(logits.permute(1, 0, 2), [4, 0] * 5):
+        assert greedy.step(step_logits).view(-1).tolist() == [token] * 2
+    sampling = SamplingSearch()
+    assert list(sampling(logits).shape) == [2, 10]
+    for step_logits in logits.permute(1, 0, 2):
+        assert list(sampling.step(step_logits).shape) == [2, 1]
+    with pytest.raises(ValueError):
+        greedy(logits[0])
+    base = [[4, 4, 4], [0, 0, 0]] * 4
+    tokens, _ = BeamSearch()(logits)
+    assert tokens.tolist() == [base + [[4, 4, 3], [0, 1, 0]]] * 2
+    tokens, _ = BeamSearch(temperature=0.001)(logits)
+    assert tokens.tolist() == [base + [[4, 4, 4], [0, 1, 2]]] * 2
+    tokens, _ = BeamSearch(temperature=3.)(logits)
+    assert tokens.tolist() == [
+        [[4, 4, 4], [0, 0, 0]] * 3 + [[4, 4, 4], [0, 0, 1], [4, 4, 4],
+                                      [0, 1, 0]]
+    ] * 2
+    tokens, _ = BeamSearch(top_tokens=2)(logits)
+    assert tokens.tolist() == [base + [[4, 4, 3], [0, 1, 0]]] * 2
+    search = BeamSearch()
+    beams = [[[list(), 0.0]]] * 2
+    for step_logits in logits.permute(1, 0, 2):
+        stacked = torch.stack([step_logits] * (search.beam_width + 1))
+        _, beams = search.step(stacked, beams)
+    got = [
+        [[int(t) for t in col] for col in zip(*[beam[0] for beam in sample])]
+        for sample in beams
+    ]
+    assert got == [base + [[4, 4, 3], [0, 1, 0]]] * 2
+
+
+def test_batch_preparation():
+    """utils/utils.py:29-168 semantics."""
+    from paccmann_chemistry_amd import utils
+    from paccmann_chemistry_amd.training import get_data_preparation
+    batch = [torch.tensor([2, 7, 8, 9, 3]), torch.tensor([2, 5, 3]),
+             torch.tensor([2, 6, 6, 3])]
+    batch = utils.collate_fn(batch)
+    assert [len(s) for s in batch] == [5, 4, 3]
+    cpu = torch.device('cpu')
+    padded = torch.nn.utils.rnn.pad_sequence(batch)
+    enc, dec, tgt = utils.sequential_data_preparation(
+        padded, input_keep=1, device=cpu)
+    assert torch.equal(enc, dec) and enc.shape == (5, 3)
+    assert torch.equal(tgt[:-1], enc[1:]) and tgt[-1].eq(0).all()
+    torch.manual_seed(0)
+    _, dec, _ = utils.sequential_data_preparation(
+        padded, input_keep=0.5, device=cpu)
+    dropped = (dec != enc).any(dim=1)
+    for t in range(5):  # whole time rows become <UNK>=1
+        if dropped[t]:
+            assert dec[t].eq(1).all()
+    enc_p, dec_p, tgt_p = utils.packed_sequential_data_preparation(
+        batch, input_keep=1, device=cpu)
+    tokens, lengths = utils.packed_to_lengths(enc_p)
+    assert lengths.tolist() == [5, 4, 3] and torch.equal(tokens, padded)
+    targets, _ = utils.packed_to_lengths(tgt_p)
+    assert targets[:, 1].tolist() == [6, 6, 3, 0, 0]
+    data, sizes = utils.perpare_packed_input(enc_p)
+    assert [len(d) for d in data] == sizes.tolist() == [3, 3, 3, 2, 1]
+    assert [len(s) for s in utils.unpack_sequence(enc_p)] == [5, 4, 3]
+    with pytest.raises(TypeError):
+        get_data_preparation(None)
+    with pytest.raises(NotImplementedError):
+        get_data_preparation('ragged')
+    enc2, _, _ = get_data_preparation('padded')(
+        batch, input_keep=1., start_index=2, end_index=3, device=cpu)
+    assert torch.equal(enc2, padded)
+
+
+def test_kl_weight_and_factories():
+    from conftest import Golden
+    from paccmann_chemistry_amd.hyperparams import (
+        OPTIMIZER_FACTORY, SEARCH_FACTORY
+    )
+    from paccmann_chemistry_amd.utils import kl_weight
+    g = Golden('kl_weight')
+    for growth in (0.0015, 0.003, 0.004):
+        got = np.array([kl_weight(int(s), growth) for s in g.data['steps']])
+        assert np.array_equal(got, g.data[f'g{growth}'])
+    assert sorted(SEARCH_FACTORY) == ['beam', 'greedy', 'sampling']
+    assert sorted(OPTIMIZER_FACTORY) == [
+        'adadelta', 'adagrad', 'adam', 'adamax', 'rmsprop', 'sgd'
+    ]
