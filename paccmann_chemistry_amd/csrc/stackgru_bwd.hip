@@ -226,8 +226,9 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(CellBwdArgs a) {
     const bool hidden_side = n0 < H;   // tile of dh[l] (uses dnh) or of dx (dni)
     const int nchunks = K3 / BCK;
 
-    f32x4 ra[2], rw[4];
-    auto load_chunk = [&](int c) {
+    // two staging register sets: prefetch distance 2 (see the forward cell)
+    f32x4 ra0[2], rw0[4], ra1[2], rw1[4];
+    auto load_chunk = [&](int c, f32x4 (&ra)[2], f32x4 (&rw)[4]) {
         int kb = c * BCK;
         // dgates columns: [0,2H) shared; third segment dni at 2H, dnh at 3H
         const int acol = (kb >= 2 * H && hidden_side) ? kb + H : kb;
@@ -235,12 +236,10 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(CellBwdArgs a) {
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx >> 4, q = idx & 15;
-            const int b = b0 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b < a.B)
-                v = *(const f32x4 *)(a.dgates + (long long)b * 4 * H + acol +
+            // rows past the batch re-read the last row (never stored)
+            const int b = min(b0 + row, a.B - 1);
+            ra[i] = *(const f32x4 *)(a.dgates + (long long)b * 4 * H + acol +
                                      q * 4);
-            ra[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -250,7 +249,7 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(CellBwdArgs a) {
                                      q * 4);
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const f32x4 (&ra)[2], const f32x4 (&rw)[4]) {
         float *As = lds + buf * (BA_TILE + BW_TILE);
         float *Ws = As + BA_TILE;
 #pragma unroll
@@ -270,12 +269,7 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(CellBwdArgs a) {
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
     const int lrow = lane & 31, lh = lane >> 5;
-    load_chunk(0);
-    int buf = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        store_chunk(buf);
-        __syncthreads();
-        if (c + 1 < nchunks) load_chunk(c + 1);
+    auto compute = [&](int buf) {
         const float *As = lds + buf * (BA_TILE + BW_TILE);
         const float *Ws = As + BA_TILE;
         const int koff = wave * 16 + 4 * lh;
@@ -295,7 +289,29 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(CellBwdArgs a) {
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][e], f1[s][e],
                                                             acc1, 0, 0, 0);
             }
-        buf ^= 1;
+    };
+
+    // unconditional loads (tail re-reads the last chunk): straight-line loop
+    // body => exact vmcnt(N) waits, see the forward cell
+    const int last = nchunks - 1;
+    load_chunk(0, ra0, rw0);
+    load_chunk(min(1, last), ra1, rw1);
+    const int npairs = nchunks >> 1;
+    for (int p = 0; p < npairs; ++p) {
+        const int c = 2 * p;
+        store_chunk(0, ra0, rw0);
+        __syncthreads();
+        load_chunk(min(c + 2, last), ra0, rw0);
+        compute(0);
+        store_chunk(1, ra1, rw1);
+        __syncthreads();
+        load_chunk(min(c + 3, last), ra1, rw1);
+        compute(1);
+    }
+    if (nchunks & 1) {
+        store_chunk(0, ra0, rw0);
+        __syncthreads();
+        compute(0);
     }
 
     __syncthreads();

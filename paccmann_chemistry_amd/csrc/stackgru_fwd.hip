@@ -31,9 +31,11 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_kernel(CellFwdArgs a) {
     const int b0 = blockIdx.y * CM;   // first batch row
     const int nchunks = a.nx_chunks + a.nh_chunks;
 
-    // staging registers: A tile 2 x float4, W tile 6 x float4 per thread
-    f32x4 ra[2], rw[6];
-    auto load_chunk = [&](int c) {
+    // staging registers: A tile 2 x float4, W tile 6 x float4 per thread and
+    // chunk; TWO register sets so that a chunk's global loads stay in flight
+    // across two compute phases (prefetch distance 2)
+    f32x4 ra0[2], rw0[6], ra1[2], rw1[6];
+    auto load_chunk = [&](int c, f32x4 (&ra)[2], f32x4 (&rw)[6]) {
         const bool xpart = c < a.nx_chunks;
         const float *src = xpart ? a.xin : a.hprev;
         const int ld = xpart ? a.ldx : a.Hp;
@@ -42,11 +44,10 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_kernel(CellFwdArgs a) {
         for (int i = 0; i < 2; ++i) {
             const int idx = tid + 256 * i;
             const int row = idx >> 4, q = idx & 15;
-            const int b = b0 + row;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (b < a.B)
-                v = *(const f32x4 *)(src + (long long)b * ld + kb + q * 4);
-            ra[i] = v;
+            // rows past the batch re-read the last row (never stored): keeps
+            // the load stream branch-free so the waitcnt counters stay exact
+            const int b = min(b0 + row, a.B - 1);
+            ra[i] = *(const f32x4 *)(src + (long long)b * ld + kb + q * 4);
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_kernel(CellFwdArgs a) {
                                      c * CK + q * 4);
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const f32x4 (&ra)[2], const f32x4 (&rw)[6]) {
         float *As = lds + buf * (A_TILE + W_TILE);
         float *Ws = As + A_TILE;
 #pragma unroll
@@ -80,12 +81,7 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_kernel(CellFwdArgs a) {
     }
 
     const int lrow = lane & 31, lh = lane >> 5;
-    load_chunk(0);
-    int buf = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        store_chunk(buf);
-        __syncthreads();
-        if (c + 1 < nchunks) load_chunk(c + 1);
+    auto compute = [&](int buf, int c) {
         const float *As = lds + buf * (A_TILE + W_TILE);
         const float *Ws = As + A_TILE;
         // this wave's 16-wide k slice; lane half lh supplies k = 8s + 4*lh + e
@@ -123,7 +119,30 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_kernel(CellFwdArgs a) {
                         fa[s][e], fn[s][e], acc_nh, 0, 0, 0);
                 }
         }
-        buf ^= 1;
+    };
+
+    // Loads are issued unconditionally (the tail re-reads the last chunk) so
+    // the loop body is straight-line and hipcc emits exact vmcnt(N) waits: the
+    // set being stored only waits for its own, older loads.
+    const int last = nchunks - 1;
+    load_chunk(0, ra0, rw0);
+    load_chunk(min(1, last), ra1, rw1);
+    const int npairs = nchunks >> 1;
+    for (int p = 0; p < npairs; ++p) {
+        const int c = 2 * p;
+        store_chunk(0, ra0, rw0);
+        __syncthreads();
+        load_chunk(min(c + 2, last), ra0, rw0);
+        compute(0, c);
+        store_chunk(1, ra1, rw1);
+        __syncthreads();
+        load_chunk(min(c + 3, last), ra1, rw1);
+        compute(1, c + 1);
+    }
+    if (nchunks & 1) {
+        store_chunk(0, ra0, rw0);
+        __syncthreads();
+        compute(0, last);
     }
 
     // cross-wave reduction of the 4 partial tiles through LDS
