@@ -486,18 +486,30 @@ int pcm_stackgru_backward(const pcm_dims *dims,
         for (int l = L - 1; l >= 0; --l) {
             float *gates = sv + lay.off_gates[l] + (size_t)t * B * 4 * H;
             float *dhl = dh + (size_t)l * B * Hp;
-            GateBwdArgs g;
-            g.dh = dhl;
-            g.dout = (l == L - 1 && d_out)
-                         ? d_out + (size_t)t * B * d_out_row_stride
-                         : nullptr;
-            g.ld_dout = d_out_row_stride;
-            g.gates = gates;
-            g.hprev = sv + lay.off_hs[l] + (size_t)t * lay.hs_step();
-            g.lengths = lengths; g.B = B; g.H = H; g.Hp = Hp; g.t = t;
-            pcm_probe_begin(PCM_K_GATE_BWD, st);
-            pcm_launch_gate_bwd(g, st);
-            pcm_probe_end(PCM_K_GATE_BWD, st);
+            // gate derivatives: the top layer (it also receives d_out and
+            // the stack-control path of step t+1) and every layer on the
+            // generic path take them in their own launch; on the fused path
+            // the lower layers' are taken in the epilogue of the cell above
+            if (l == L - 1 || !fused_bwd) {
+                GateBwdArgs g;
+                memset(&g, 0, sizeof(g));
+                g.dh = dhl;
+                g.dout = (l == L - 1 && d_out)
+                             ? d_out + (size_t)t * B * d_out_row_stride
+                             : nullptr;
+                g.ld_dout = d_out_row_stride;
+                g.gates = gates;
+                g.hprev = sv + lay.off_hs[l] + (size_t)t * lay.hs_step();
+                g.lengths = lengths; g.B = B; g.H = H; g.Hp = Hp; g.t = t;
+                if (l == L - 1 && lay.use_stack && t + 1 < T) {
+                    g.dcu = sv + lay.av_index(t + 1);
+                    g.ctrl_w = weights->ctrl_w; g.push_w = weights->push_w;
+                    g.W = lay.W; g.AVW = lay.AVW;
+                }
+                pcm_probe_begin(PCM_K_GATE_BWD, st);
+                pcm_launch_gate_bwd(g, st);
+                pcm_probe_end(PCM_K_GATE_BWD, st);
+            }
 
             if (fused_bwd) {
                 CellBwdArgs cb;
@@ -514,6 +526,14 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                 cb.drop_p = (l > 0 && drop) ? dropout_p : 0.f;
                 cb.inv_keep = cb.drop_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
                 cb.seed = seed;
+                cb.gates_low = nullptr; cb.hprev_low = nullptr;
+                cb.lengths = lengths;
+                if (l > 0) {
+                    cb.gates_low = sv + lay.off_gates[l - 1] +
+                                   (size_t)t * B * 4 * H;
+                    cb.hprev_low = sv + lay.off_hs[l - 1] +
+                                   (size_t)t * lay.hs_step();
+                }
                 pcm_probe_begin(PCM_K_GEMM, st);
                 pcm_launch_cell_bwd(cb, st);
                 pcm_probe_end(PCM_K_GEMM, st);
@@ -573,8 +593,6 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             s.dtop = dtop;
             s.S_prev = sv + lay.s_index(t);
             s.av = sv + lay.av_index(t);
-            s.ctrl_w = weights->ctrl_w; s.push_w = weights->push_w;
-            s.dh_top = dh + (size_t)(L - 1) * B * Hp;
             s.lengths = lengths;
             s.B = B; s.H = H; s.Hp = Hp; s.D = lay.D; s.W = lay.W;
             s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
@@ -583,6 +601,17 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             pcm_probe_end(PCM_K_STACK_BWD, st);
             cur ^= 1;
         }
+    }
+    if (lay.use_stack) {
+        // the control path of step 0 reaches the initial top-layer hidden
+        GateBwdArgs g;
+        memset(&g, 0, sizeof(g));
+        g.dh = dh + (size_t)(L - 1) * B * Hp;
+        g.dcu = sv + lay.av_index(0);
+        g.ctrl_w = weights->ctrl_w; g.push_w = weights->push_w;
+        g.W = lay.W; g.AVW = lay.AVW;
+        g.B = B; g.H = H; g.Hp = Hp; g.t = -1; g.ctrl_only = 1;
+        pcm_launch_gate_bwd(g, st);
     }
     if (d_h0)
         for (int l = 0; l < L; ++l)

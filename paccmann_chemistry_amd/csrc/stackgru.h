@@ -109,8 +109,12 @@ struct GateBwdArgs {
     float *gates;         // [B, 4H] in: r,z,n,ghn ; out: dr,dz,dni,dnh
     const float *hprev;   // [B, Hp]
     const int32_t *lengths;
+    // stack-control path of the step above (top layer only, nullable):
+    // dL/dh_t += dc.Wc + du.Ws with [dc,du] = dcu[b][0..3+W)
+    const float *dcu, *ctrl_w, *push_w;
     long long ld_dout;
-    int B, H, Hp, t;
+    int B, H, Hp, t, W, AVW;
+    int ctrl_only;        // 1: only add the control path into dh (no gates)
 };
 int pcm_launch_gate_bwd(const GateBwdArgs &a, hipStream_t stream);
 
@@ -129,6 +133,11 @@ struct CellBwdArgs {
     int t, layer;
     float drop_p, inv_keep;  // drop_p > 0: mask dx with the forward's dropout
     uint64_t seed;
+    // fused gate gradient of the layer below (l > 0): once dx completes
+    // dL/dh_t of layer l-1, its gate derivatives are taken in the epilogue
+    float *gates_low;        // [B, 4H] in: r,z,n,ghn ; out: dr,dz,dni,dnh (nullable)
+    const float *hprev_low;  // [B, Hp]
+    const int32_t *lengths;
 };
 int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream);
 
@@ -144,9 +153,8 @@ struct StackBwdArgs {
     float *dS_prev;       // [B, D*W] dL/dS_{t-1}
     const float *dtop;    // [B, Wp] gradient of the stack top fed to layer 0
     const float *S_prev;  // [B, D*W]
-    float *av;            // [B, AVW] in: a,v ; out: dc, du
-    const float *ctrl_w, *push_w;
-    float *dh_top;        // [B, Hp] += dc.Wc + du.Ws
+    float *av;            // [B, AVW] in: a,v ; out: dc, du (consumed by the
+                          // top layer's gate_bwd of the step below)
     const int32_t *lengths;
     int B, H, Hp, D, W, Wp, AVW, t;
 };

@@ -11,35 +11,53 @@
 
 namespace {
 
+__device__ __forceinline__ void gate_grad(float d, float *g, int H, int j,
+                                          float hp, float *dh_out) {
+    const float r = g[j], z = g[H + j], n = g[2 * H + j], ghn = g[3 * H + j];
+    const float dn = d * (1.f - z);
+    const float dz = d * (hp - n);
+    const float dpn = dn * (1.f - n * n);
+    const float dpz = dz * z * (1.f - z);
+    const float dr = dpn * ghn;
+    const float dpr = dr * r * (1.f - r);
+    g[j] = dpr;
+    g[H + j] = dpz;
+    g[2 * H + j] = dpn;       // d(W_in.x + b_in)
+    g[3 * H + j] = dpn * r;   // d(W_hn.h + b_hn)
+    *dh_out = d * z;
+}
+
 __global__ __launch_bounds__(256) void gate_bwd_kernel(GateBwdArgs a) {
     const long long total = (long long)a.B * a.H;
+    const int NO = 3 + a.W;
     for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * 256) {
         const int b = (int)(idx / a.H), j = (int)(idx - (long long)b * a.H);
-        float *g = a.gates + (long long)b * 4 * a.H;
         float *dh = a.dh + (long long)b * a.Hp + j;
         float d = *dh;
+        if (a.dcu) {
+            // stack-control path of step t+1 (zero for rows frozen there)
+            const float *dc = a.dcu + (long long)b * a.AVW;
+            float s = 0.f;
+#pragma unroll
+            for (int o = 0; o < 3; ++o)
+                s = fmaf(dc[o], a.ctrl_w[(long long)o * a.H + j], s);
+#pragma unroll 8
+            for (int o = 3; o < NO; ++o)
+                s = fmaf(dc[o], a.push_w[(long long)(o - 3) * a.H + j], s);
+            d += s;
+        }
+        if (a.ctrl_only) { *dh = d; continue; }
+        float *g = a.gates + (long long)b * 4 * a.H;
         if (a.lengths && a.t >= a.lengths[b]) {
-            // frozen row: h_t = h_{t-1}; its (zeroed) output carries no gradient
+            // frozen row: h_t = h_{t-1}; its output carries no gradient
             g[j] = 0.f; g[a.H + j] = 0.f; g[2 * a.H + j] = 0.f;
             g[3 * a.H + j] = 0.f;
+            *dh = d;
             continue;
         }
         if (a.dout) d += a.dout[(long long)b * a.ld_dout + j];
-        const float r = g[j], z = g[a.H + j], n = g[2 * a.H + j],
-                    ghn = g[3 * a.H + j];
-        const float hp = a.hprev[(long long)b * a.Hp + j];
-        const float dn = d * (1.f - z);
-        const float dz = d * (hp - n);
-        const float dpn = dn * (1.f - n * n);
-        const float dpz = dz * z * (1.f - z);
-        const float dr = dpn * ghn;
-        const float dpr = dr * r * (1.f - r);
-        g[j] = dpr;
-        g[a.H + j] = dpz;
-        g[2 * a.H + j] = dpn;       // d(W_in.x + b_in)
-        g[3 * a.H + j] = dpn * r;   // d(W_hn.h + b_hn)
-        *dh = d * z;
+        gate_grad(d, g, a.H, j, a.hprev[(long long)b * a.Hp + j], dh);
     }
 }
 
@@ -51,7 +69,7 @@ constexpr int BTHREADS = 512;
 
 __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int W = a.W, D = a.D, DW = D * W, H = a.H;
+    const int W = a.W, D = a.D, DW = D * W;
     const int DWp = (DW + 3) & ~3;
     float *Srow = sm;                       // [BROWS][DWp]  S_{t-1}
     float *Grow = Srow + BROWS * DWp;       // [BROWS][DWp]  dL/dS'_t (+ dtop)
@@ -183,22 +201,6 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
         const int r = idx / a.AVW, o = idx - r * a.AVW;
         const int b = b0 + r;
         if (b < a.B) a.av[(long long)b * a.AVW + o] = dcu[idx];
-    }
-    // dL/dh_top += dc.Wc + du.Ws
-    for (int idx = tid; idx < BROWS * H; idx += BTHREADS) {
-        const int r = idx / H, j = idx - r * H;
-        const int b = b0 + r;
-        if (b >= a.B) continue;
-        if (a.lengths && a.t >= a.lengths[b]) continue;
-        const float *out = dcu + r * a.AVW;
-        float s = 0.f;
-#pragma unroll
-        for (int o = 0; o < 3; ++o)
-            s = fmaf(out[o], a.ctrl_w[(long long)o * H + j], s);
-#pragma unroll 10
-        for (int w = 0; w < W; ++w)
-            s = fmaf(out[3 + w], a.push_w[(long long)w * H + j], s);
-        a.dh_top[(long long)b * a.Hp + j] += s;
     }
 }
 
@@ -344,7 +346,22 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(CellBwdArgs a) {
                 v *= pcm_dropout_scale(a.seed, a.layer, a.t, b, j, a.drop_p,
                                        a.inv_keep);
             float *dst = a.dx + (long long)b * a.ldx + j;
-            *dst = a.dx_accumulate ? *dst + v : v;
+            if (a.gates_low) {
+                // v completes dL/dh_t of the layer below: take its gate
+                // derivatives right here (saves a launch per step)
+                const float d = *dst + v;
+                float *g = a.gates_low + (long long)b * 4 * H;
+                if (a.lengths && a.t >= a.lengths[b]) {
+                    g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f;
+                    g[3 * H + j] = 0.f;
+                    *dst = d;
+                } else {
+                    gate_grad(d, g, H, j,
+                              a.hprev_low[(long long)b * a.Hp + j], dst);
+                }
+            } else {
+                *dst = a.dx_accumulate ? *dst + v : v;
+            }
         }
     }
 }

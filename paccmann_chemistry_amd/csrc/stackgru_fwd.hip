@@ -226,6 +226,25 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * SROWS;
 
+    // control / push weights of this wave's outputs go to registers FIRST so
+    // their L2 round trip overlaps the staging loads below (H <= 512 path)
+    constexpr int KS = 8;
+    const bool wregs = H <= 64 * KS && NO <= 8 * SOUT;
+    float wr[SOUT][KS];
+    if (wregs) {
+#pragma unroll
+        for (int i = 0; i < SOUT; ++i) {
+            const int o = min(wave * SOUT + i, NO - 1);
+            const float *wrow = o < 3 ? a.ctrl_w + (long long)o * H
+                                      : a.push_w + (long long)(o - 3) * H;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) {
+                const int k = lane + 64 * kk;
+                wr[i][kk] = k < H ? wrow[k] : 0.f;
+            }
+        }
+    }
+
     // stage previous stacks (vectorised when the row size allows it)
     if ((DW & 3) == 0) {
         const int nq = DW >> 2;
@@ -252,6 +271,47 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
     __syncthreads();
 
     // dot products: wave handles SOUT outputs per pass, lanes stride K
+    if (wregs) {
+        float p[SOUT][SROWS];
+#pragma unroll
+        for (int i = 0; i < SOUT; ++i)
+#pragma unroll
+            for (int r = 0; r < SROWS; ++r) p[i][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            const int k = lane + 64 * kk;
+            if (k < H) {
+#pragma unroll
+                for (int r = 0; r < SROWS; ++r) {
+                    const float hv = hrow[r * H + k];
+#pragma unroll
+                    for (int i = 0; i < SOUT; ++i)
+                        p[i][r] = fmaf(wr[i][kk], hv, p[i][r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SOUT; ++i)
+#pragma unroll
+            for (int r = 0; r < SROWS; ++r) {
+                float v = p[i][r];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                p[i][r] = v;
+            }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < SOUT; ++i) {
+                const int o = wave * SOUT + i;
+                if (o < NO) {
+                    const float bias = o < 3 ? a.ctrl_b[o] : a.push_b[o - 3];
+#pragma unroll
+                    for (int r = 0; r < SROWS; ++r)
+                        cu[r * a.AVW + o] = p[i][r] + bias;
+                }
+            }
+        }
+    } else
     for (int obase = wave * SOUT; obase < NO; obase += 8 * SOUT) {
         float p[SOUT][SROWS];
         const float *wrow[SOUT];
