@@ -94,6 +94,11 @@ static inline void pcm_probe_end(int id, hipStream_t st) {
 }
 
 // ---- device helpers -------------------------------------------------------------
+// n / d for 0 <= n < 2^20 through a float reciprocal (3 VALU instead of ~35):
+// n + 0.5 is never within 0.5 of a multiple of d, far above fp32 rounding.
+__device__ __forceinline__ int pcm_fdiv(int n, float inv_d) {
+    return (int)(((float)n + 0.5f) * inv_d);
+}
 __device__ __forceinline__ float pcm_sigmoid(float x) {
     return 1.0f / (1.0f + expf(-x));
 }

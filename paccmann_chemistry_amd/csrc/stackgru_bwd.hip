@@ -28,37 +28,37 @@ __device__ __forceinline__ void gate_grad(float d, float *g, int H, int j,
 }
 
 __global__ __launch_bounds__(256) void gate_bwd_kernel(GateBwdArgs a) {
-    const long long total = (long long)a.B * a.H;
+    // grid: x = blocks of 256 hidden units, y = batch row (wave-uniform row =>
+    // the control gradients of the row are scalar loads)
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.H) return;
     const int NO = 3 + a.W;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * 256) {
-        const int b = (int)(idx / a.H), j = (int)(idx - (long long)b * a.H);
-        float *dh = a.dh + (long long)b * a.Hp + j;
-        float d = *dh;
-        if (a.dcu) {
-            // stack-control path of step t+1 (zero for rows frozen there)
-            const float *dc = a.dcu + (long long)b * a.AVW;
-            float s = 0.f;
+    float *dh = a.dh + (long long)b * a.Hp + j;
+    float d = *dh;
+    if (a.dcu) {
+        // stack-control path of step t+1 (zero for rows frozen there)
+        const float *dc = a.dcu + (long long)b * a.AVW;
+        float s = 0.f;
 #pragma unroll
-            for (int o = 0; o < 3; ++o)
-                s = fmaf(dc[o], a.ctrl_w[(long long)o * a.H + j], s);
-#pragma unroll 8
-            for (int o = 3; o < NO; ++o)
-                s = fmaf(dc[o], a.push_w[(long long)(o - 3) * a.H + j], s);
-            d += s;
-        }
-        if (a.ctrl_only) { *dh = d; continue; }
-        float *g = a.gates + (long long)b * 4 * a.H;
-        if (a.lengths && a.t >= a.lengths[b]) {
-            // frozen row: h_t = h_{t-1}; its output carries no gradient
-            g[j] = 0.f; g[a.H + j] = 0.f; g[2 * a.H + j] = 0.f;
-            g[3 * a.H + j] = 0.f;
-            *dh = d;
-            continue;
-        }
-        if (a.dout) d += a.dout[(long long)b * a.ld_dout + j];
-        gate_grad(d, g, a.H, j, a.hprev[(long long)b * a.Hp + j], dh);
+        for (int o = 0; o < 3; ++o)
+            s = fmaf(dc[o], a.ctrl_w[(long long)o * a.H + j], s);
+#pragma unroll 16
+        for (int o = 3; o < NO; ++o)
+            s = fmaf(dc[o], a.push_w[(long long)(o - 3) * a.H + j], s);
+        d += s;
     }
+    if (a.ctrl_only) { *dh = d; return; }
+    float *g = a.gates + (long long)b * 4 * a.H;
+    if (a.lengths && a.t >= a.lengths[b]) {
+        // frozen row: h_t = h_{t-1}; its output carries no gradient
+        g[j] = 0.f; g[a.H + j] = 0.f; g[2 * a.H + j] = 0.f;
+        g[3 * a.H + j] = 0.f;
+        *dh = d;
+        return;
+    }
+    if (a.dout) d += a.dout[(long long)b * a.ld_dout + j];
+    gate_grad(d, g, a.H, j, a.hprev[(long long)b * a.Hp + j], dh);
 }
 
 // One block of 512 threads per BROWS batch rows.  S_{t-1} and dL/dS'_t of the
@@ -71,6 +71,10 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int W = a.W, D = a.D, DW = D * W;
     const int DWp = (DW + 3) & ~3;
+    const float inv_DW = 1.0f / (float)DW, inv_W = 1.0f / (float)W;
+    const float inv_AVW = 1.0f / (float)a.AVW;
+    const float inv_AV3 = 1.0f / (float)max(a.AVW - 3, 1);
+    const float inv_nq = 1.0f / (float)max(DW >> 2, 1);
     float *Srow = sm;                       // [BROWS][DWp]  S_{t-1}
     float *Grow = Srow + BROWS * DWp;       // [BROWS][DWp]  dL/dS'_t (+ dtop)
     float *avs = Grow + BROWS * DWp;        // [BROWS][AVW]  a, v
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
     if ((DW & 3) == 0) {
         const int nq = DW >> 2;
         for (int idx = tid; idx < BROWS * nq; idx += BTHREADS) {
-            const int r = idx / nq, q = idx - r * nq;
+            const int r = pcm_fdiv(idx, inv_nq), q = idx - r * nq;
             const int b = b0 + r;
             f32x4 sv = {0.f, 0.f, 0.f, 0.f}, gv = {0.f, 0.f, 0.f, 0.f};
             if (b < a.B) {
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
         }
     } else {
         for (int idx = tid; idx < BROWS * DW; idx += BTHREADS) {
-            const int r = idx / DW, e = idx - r * DW;
+            const int r = pcm_fdiv(idx, inv_DW), e = idx - r * DW;
             const int b = b0 + r;
             const bool ok = b < a.B;
             Srow[r * DWp + e] = ok ? a.S_prev[(long long)b * DW + e] : 0.f;
@@ -104,14 +108,14 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
         }
     }
     for (int idx = tid; idx < BROWS * a.AVW; idx += BTHREADS) {
-        const int r = idx / a.AVW, o = idx - r * a.AVW;
+        const int r = pcm_fdiv(idx, inv_AVW), o = idx - r * a.AVW;
         const int b = b0 + r;
         avs[idx] = b < a.B ? a.av[(long long)b * a.AVW + o] : 0.f;
     }
     __syncthreads();
     // the stack top fed layer 0: its gradient joins row 0 of G
     for (int idx = tid; idx < BROWS * W; idx += BTHREADS) {
-        const int r = idx / W, w = idx - r * W;
+        const int r = pcm_fdiv(idx, inv_W), w = idx - r * W;
         const int b = b0 + r;
         if (b < a.B && !(a.lengths && a.t >= a.lengths[b]))
             Grow[r * DWp + w] += a.dtop[(long long)b * a.Wp + w];
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
         for (int e = tid; e < DW; e += BTHREADS) {
             const float g = G[e];
             if (frozen) { dSp[e] = g; continue; }
-            const int d = e / W, w = e - d * W;
+            const int d = pcm_fdiv(e, inv_W), w = e - d * W;
             const float s = Sp[e];
             const float up = d == 0 ? c[3 + w] : Sp[e - W];
             const float dn = d == D - 1 ? 0.f : Sp[e + W];
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
     }
     // dv[w] = a_push * G[0][w]; du = dv * (1 - v^2); zero the padding
     for (int idx = tid; idx < BROWS * (a.AVW - 3); idx += BTHREADS) {
-        const int r = idx / (a.AVW - 3), w = idx - r * (a.AVW - 3);
+        const int r = pcm_fdiv(idx, inv_AV3), w = idx - r * (a.AVW - 3);
         const int b = b0 + r;
         const bool frozen = b < a.B && a.lengths && a.t >= a.lengths[b];
         float val = 0.f;
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
     __syncthreads();
     // keep dc/du for the time-parallel dWc / dWs products
     for (int idx = tid; idx < BROWS * a.AVW; idx += BTHREADS) {
-        const int r = idx / a.AVW, o = idx - r * a.AVW;
+        const int r = pcm_fdiv(idx, inv_AVW), o = idx - r * a.AVW;
         const int b = b0 + r;
         if (b < a.B) a.av[(long long)b * a.AVW + o] = dcu[idx];
     }
@@ -230,26 +234,29 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(CellBwdArgs a) {
 
     // two staging register sets: prefetch distance 2 (see the forward cell)
     f32x4 ra0[2], rw0[4], ra1[2], rw1[4];
+    const float *ap[2], *wp[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 4, q = idx & 15;
+        // rows past the batch re-read the last row (never stored)
+        const int b = min(b0 + row, a.B - 1);
+        ap[i] = a.dgates + (long long)b * 4 * H + q * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 4, q = idx & 15;  // row 0..63
+        wp[i] = a.wpackT + (long long)(n0 + row) * K3 + q * 4;
+    }
     auto load_chunk = [&](int c, f32x4 (&ra)[2], f32x4 (&rw)[4]) {
-        int kb = c * BCK;
+        const int kb = c * BCK;
         // dgates columns: [0,2H) shared; third segment dni at 2H, dnh at 3H
         const int acol = (kb >= 2 * H && hidden_side) ? kb + H : kb;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx >> 4, q = idx & 15;
-            // rows past the batch re-read the last row (never stored)
-            const int b = min(b0 + row, a.B - 1);
-            ra[i] = *(const f32x4 *)(a.dgates + (long long)b * 4 * H + acol +
-                                     q * 4);
-        }
+        for (int i = 0; i < 2; ++i) ra[i] = *(const f32x4 *)(ap[i] + acol);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx >> 4, q = idx & 15;  // row 0..63
-            rw[i] = *(const f32x4 *)(a.wpackT + (long long)(n0 + row) * K3 + kb +
-                                     q * 4);
-        }
+        for (int i = 0; i < 4; ++i) rw[i] = *(const f32x4 *)(wp[i] + kb);
     };
     auto store_chunk = [&](int buf, const f32x4 (&ra)[2], const f32x4 (&rw)[4]) {
         float *As = lds + buf * (BA_TILE + BW_TILE);
@@ -418,8 +425,8 @@ int grid_for(long long n) {
 }  // namespace
 
 int pcm_launch_gate_bwd(const GateBwdArgs &a, hipStream_t stream) {
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3(grid_for((long long)a.B * a.H)),
-                       dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3((a.H + 255) / 256, a.B), dim3(256),
+                       0, stream, a);
     return 0;
 }
 

@@ -35,29 +35,34 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_kernel(CellFwdArgs a) {
     // chunk; TWO register sets so that a chunk's global loads stay in flight
     // across two compute phases (prefetch distance 2)
     f32x4 ra0[2], rw0[6], ra1[2], rw1[6];
+    // per-thread source pointers are computed once; a chunk only adds a
+    // wave-uniform K offset (keeps 64-bit address VALU out of the MFMA loop)
+    const float *ax[2], *ah[2], *wp[6];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 4, q = idx & 15;
+        // rows past the batch re-read the last row (never stored): keeps the
+        // load stream branch-free so the waitcnt counters stay exact
+        const int b = min(b0 + row, a.B - 1);
+        ax[i] = a.xin + (long long)b * a.ldx + q * 4;
+        ah[i] = a.hprev + (long long)b * a.Hp + q * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int idx = tid + 256 * i;
+        const int row = idx >> 4, q = idx & 15;  // row 0..95
+        const int g = row >> 5, jj = row & 31;
+        wp[i] = a.wpack + (long long)(g * a.Hn + j0 + jj) * a.Kp + q * 4;
+    }
     auto load_chunk = [&](int c, f32x4 (&ra)[2], f32x4 (&rw)[6]) {
         const bool xpart = c < a.nx_chunks;
-        const float *src = xpart ? a.xin : a.hprev;
-        const int ld = xpart ? a.ldx : a.Hp;
         const int kb = (xpart ? c : c - a.nx_chunks) * CK;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx >> 4, q = idx & 15;
-            // rows past the batch re-read the last row (never stored): keeps
-            // the load stream branch-free so the waitcnt counters stay exact
-            const int b = min(b0 + row, a.B - 1);
-            ra[i] = *(const f32x4 *)(src + (long long)b * ld + kb + q * 4);
-        }
+        for (int i = 0; i < 2; ++i)
+            ra[i] = *(const f32x4 *)((xpart ? ax[i] : ah[i]) + kb);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int idx = tid + 256 * i;
-            const int row = idx >> 4, q = idx & 15;  // row 0..95
-            const int g = row >> 5, jj = row & 31;
-            rw[i] = *(const f32x4 *)(a.wpack +
-                                     (long long)(g * a.Hn + j0 + jj) * a.Kp +
-                                     c * CK + q * 4);
-        }
+        for (int i = 0; i < 6; ++i) rw[i] = *(const f32x4 *)(wp[i] + c * CK);
     };
     auto store_chunk = [&](int buf, const f32x4 (&ra)[2], const f32x4 (&rw)[6]) {
         float *As = lds + buf * (A_TILE + W_TILE);
@@ -220,6 +225,9 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int H = a.H, W = a.W, D = a.D, DW = D * W, NO = 3 + W;
     const int DWp = (DW + 3) & ~3;
+    const float inv_DW = 1.0f / (float)DW, inv_W = 1.0f / (float)W;
+    const float inv_H = 1.0f / (float)H, inv_AVW = 1.0f / (float)a.AVW;
+    const float inv_nq = 1.0f / (float)max(DW >> 2, 1);
     float *Srow = sm;                          // [SROWS][DWp]
     float *hrow = Srow + SROWS * DWp;          // [SROWS][H]
     float *cu = hrow + SROWS * H;              // [SROWS][AVW]
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
     if ((DW & 3) == 0) {
         const int nq = DW >> 2;
         for (int idx = tid; idx < SROWS * nq; idx += STHREADS) {
-            const int r = idx / nq, q = idx - r * nq;
+            const int r = pcm_fdiv(idx, inv_nq), q = idx - r * nq;
             const int b = b0 + r;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (b < a.B)
@@ -258,13 +266,13 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
         }
     } else {
         for (int idx = tid; idx < SROWS * DW; idx += STHREADS) {
-            const int r = idx / DW, e = idx - r * DW;
+            const int r = pcm_fdiv(idx, inv_DW), e = idx - r * DW;
             const int b = b0 + r;
             Srow[r * DWp + e] = b < a.B ? a.S_prev[(long long)b * DW + e] : 0.f;
         }
     }
     for (int idx = tid; idx < SROWS * H; idx += STHREADS) {
-        const int r = idx / H, k = idx - r * H;
+        const int r = pcm_fdiv(idx, inv_H), k = idx - r * H;
         const int b = b0 + r;
         hrow[idx] = b < a.B ? a.htop[(long long)b * a.Hp + k] : 0.f;
     }
@@ -368,22 +376,22 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
         c[0] = e0 / s; c[1] = e1 / s; c[2] = e2 / s;
     }
     for (int idx = tid; idx < SROWS * W; idx += STHREADS) {
-        const int r = idx / W, w = idx - r * W;
+        const int r = pcm_fdiv(idx, inv_W), w = idx - r * W;
         cu[r * a.AVW + 3 + w] = tanhf(cu[r * a.AVW + 3 + w]);
     }
     __syncthreads();
 
     // record a, v (needed by the reverse pass) and update the stack
     for (int idx = tid; idx < SROWS * a.AVW; idx += STHREADS) {
-        const int r = idx / a.AVW, o = idx - r * a.AVW;
+        const int r = pcm_fdiv(idx, inv_AVW), o = idx - r * a.AVW;
         const int b = b0 + r;
         if (b < a.B) a.av[(long long)b * a.AVW + o] = o < NO ? cu[idx] : 0.f;
     }
     for (int idx = tid; idx < SROWS * DW; idx += STHREADS) {
-        const int r = idx / DW, e = idx - r * DW;
+        const int r = pcm_fdiv(idx, inv_DW), e = idx - r * DW;
         const int b = b0 + r;
         if (b >= a.B) continue;
-        const int d = e / W, w = e - d * W;
+        const int d = pcm_fdiv(e, inv_W), w = e - d * W;
         const float *Sp = Srow + r * DWp;
         const float s = Sp[e];
         float nv = s;
@@ -399,8 +407,9 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
         if (d == 0) a.xtop[(long long)b * a.Wp + w] = nv;
     }
     const int padw = a.Wp - W;
+    const float inv_padw = 1.0f / (float)max(padw, 1);
     for (int idx = tid; idx < SROWS * padw; idx += STHREADS) {
-        const int r = idx / padw, w = W + idx - r * padw;
+        const int r = pcm_fdiv(idx, inv_padw), w = W + idx - r * padw;
         const int b = b0 + r;
         if (b < a.B) a.xtop[(long long)b * a.Wp + w] = 0.f;
     }
