@@ -20,64 +20,27 @@ constexpr int CM = 32;        // batch rows per block
 constexpr int CN = 32;        // hidden units per block (x3 gates)
 constexpr int A_TILE = CM * LDT;
 constexpr int W_TILE = 3 * CN * LDT;
-constexpr int CELL_LDS = 2 * (A_TILE + W_TILE);  // floats (69632 B)
+constexpr int STAGE = A_TILE + W_TILE;     // floats per LDS stage (34816 B)
+constexpr int NSTAGE = 3;
+constexpr int CELL_LDS = NSTAGE * STAGE;   // 104448 B
 static_assert(CELL_LDS >= 4 * 4 * 1024, "reduction buffer must fit");
 
-__global__ __launch_bounds__(256) void gru_cell_fwd_kernel(CellFwdArgs a) {
+// Wave-specialised: waves 0-3 ("consumers", one per SIMD) only read operand
+// fragments from LDS and issue MFMAs; waves 4-7 ("loaders", the SIMD partners)
+// stream the operand chunks global -> registers -> LDS two chunks ahead.  One
+// workgroup barrier per chunk hands stage c+2 to the consumers, which prefetch
+// the fragments of chunk c+1 while the MFMAs of chunk c run, so global-load
+// latency, ds_write and ds_read all sit in the shadow of the matrix pipe.
+__global__ __launch_bounds__(512) void gru_cell_fwd_kernel(CellFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[CELL_LDS];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int j0 = blockIdx.x * CN;   // first hidden unit of the tile
     const int b0 = blockIdx.y * CM;   // first batch row
     const int nchunks = a.nx_chunks + a.nh_chunks;
-
-    // staging registers: A tile 2 x float4, W tile 6 x float4 per thread and
-    // chunk; TWO register sets so that a chunk's global loads stay in flight
-    // across two compute phases (prefetch distance 2)
-    f32x4 ra0[2], rw0[6], ra1[2], rw1[6];
-    // per-thread source pointers are computed once; a chunk only adds a
-    // wave-uniform K offset (keeps 64-bit address VALU out of the MFMA loop)
-    const float *ax[2], *ah[2], *wp[6];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = tid + 256 * i;
-        const int row = idx >> 4, q = idx & 15;
-        // rows past the batch re-read the last row (never stored): keeps the
-        // load stream branch-free so the waitcnt counters stay exact
-        const int b = min(b0 + row, a.B - 1);
-        ax[i] = a.xin + (long long)b * a.ldx + q * 4;
-        ah[i] = a.hprev + (long long)b * a.Hp + q * 4;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int idx = tid + 256 * i;
-        const int row = idx >> 4, q = idx & 15;  // row 0..95
-        const int g = row >> 5, jj = row & 31;
-        wp[i] = a.wpack + (long long)(g * a.Hn + j0 + jj) * a.Kp + q * 4;
-    }
-    auto load_chunk = [&](int c, f32x4 (&ra)[2], f32x4 (&rw)[6]) {
-        const bool xpart = c < a.nx_chunks;
-        const int kb = (xpart ? c : c - a.nx_chunks) * CK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            ra[i] = *(const f32x4 *)((xpart ? ax[i] : ah[i]) + kb);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) rw[i] = *(const f32x4 *)(wp[i] + c * CK);
-    };
-    auto store_chunk = [&](int buf, const f32x4 (&ra)[2], const f32x4 (&rw)[6]) {
-        float *As = lds + buf * (A_TILE + W_TILE);
-        float *Ws = As + A_TILE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            *(f32x4 *)(As + (idx >> 4) * LDT + (idx & 15) * 4) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int idx = tid + 256 * i;
-            *(f32x4 *)(Ws + (idx >> 4) * LDT + (idx & 15) * 4) = rw[i];
-        }
-    };
+    const int last = nchunks - 1;
+    const int npad = (nchunks + 3) & ~3;  // both roles run npad barriers
+    const int lrow = lane & 31, lh = lane >> 5;
 
     f32x16 acc_r, acc_z, acc_ni, acc_nh;
 #pragma unroll
@@ -85,89 +48,157 @@ __global__ __launch_bounds__(256) void gru_cell_fwd_kernel(CellFwdArgs a) {
         acc_r[r] = 0.f; acc_z[r] = 0.f; acc_ni[r] = 0.f; acc_nh[r] = 0.f;
     }
 
-    const int lrow = lane & 31, lh = lane >> 5;
-    auto compute = [&](int buf, int c) {
-        const float *As = lds + buf * (A_TILE + W_TILE);
-        const float *Ws = As + A_TILE;
+    if (wave >= 4) {
+        // ---------------- loader waves ----------------
+        const int lt = tid - 256;
+        const float *ax[2], *ah[2], *wp[6];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = lt + 256 * i;
+            const int row = idx >> 4, q = idx & 15;
+            // rows past the batch re-read the last row (never stored)
+            const int b = min(b0 + row, a.B - 1);
+            ax[i] = a.xin + (long long)b * a.ldx + q * 4;
+            ah[i] = a.hprev + (long long)b * a.Hp + q * 4;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int idx = lt + 256 * i;
+            const int row = idx >> 4, q = idx & 15;  // row 0..95
+            const int g = row >> 5, jj = row & 31;
+            wp[i] = a.wpack + (long long)(g * a.Hn + j0 + jj) * a.Kp + q * 4;
+        }
+        // FOUR staging register sets: a chunk's loads are issued 4-6 chunks
+        // before its data is needed (128 KB in flight per CU), which is what
+        // the loaded-L2 latency asks for.  Loads are unconditional (the tail
+        // re-reads the last chunk) and the loop runs a whole number of groups
+        // of 4, so the body is straight-line and hipcc emits exact vmcnt(N).
+        f32x4 ra[4][2], rw[4][6];
+        auto load_chunk = [&](int c, f32x4 (&qa)[2], f32x4 (&qw)[6]) {
+            c = min(c, last);
+            const bool xpart = c < a.nx_chunks;
+            const int kb = (xpart ? c : c - a.nx_chunks) * CK;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                qa[i] = *(const f32x4 *)((xpart ? ax[i] : ah[i]) + kb);
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                qw[i] = *(const f32x4 *)(wp[i] + c * CK);
+        };
+        auto store_chunk = [&](int stage, const f32x4 (&qa)[2],
+                               const f32x4 (&qw)[6]) {
+            float *As = lds + stage * STAGE;
+            float *Ws = As + A_TILE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = lt + 256 * i;
+                *(f32x4 *)(As + (idx >> 4) * LDT + (idx & 15) * 4) = qa[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int idx = lt + 256 * i;
+                *(f32x4 *)(Ws + (idx >> 4) * LDT + (idx & 15) * 4) = qw[i];
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_chunk(i, ra[i], rw[i]);
+        store_chunk(0, ra[0], rw[0]);
+        load_chunk(4, ra[0], rw[0]);
+        store_chunk(1, ra[1], rw[1]);
+        load_chunk(5, ra[1], rw[1]);
+        __syncthreads();  // barrier #0: stages 0 and 1 are ready
+        int stage = 2;    // stage of chunk c + 2
+        for (int c = 0; c < npad; c += 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                // chunk c + i + 2 lives in register set (i + 2) & 3
+                store_chunk(stage, ra[(i + 2) & 3], rw[(i + 2) & 3]);
+                load_chunk(c + i + 6, ra[(i + 2) & 3], rw[(i + 2) & 3]);
+                stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+                __syncthreads();
+            }
+        }
+    } else {
+        // ---------------- consumer waves ----------------
         // this wave's 16-wide k slice; lane half lh supplies k = 8s + 4*lh + e
         const int koff = wave * 16 + 4 * lh;
-        f32x4 fa[2], fr[2], fz[2], fn[2];
+        f32x4 fa0[2], fr0[2], fz0[2], fn0[2];
+        f32x4 fa1[2], fr1[2], fz1[2], fn1[2];
+        auto read_frags = [&](int stage, f32x4 (&fa)[2], f32x4 (&fr)[2],
+                              f32x4 (&fz)[2], f32x4 (&fn)[2]) {
+            const float *As = lds + stage * STAGE;
+            const float *Ws = As + A_TILE;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            fa[s] = *(const f32x4 *)(As + lrow * LDT + koff + 8 * s);
-            fr[s] = *(const f32x4 *)(Ws + (0 * CN + lrow) * LDT + koff + 8 * s);
-            fz[s] = *(const f32x4 *)(Ws + (1 * CN + lrow) * LDT + koff + 8 * s);
-            fn[s] = *(const f32x4 *)(Ws + (2 * CN + lrow) * LDT + koff + 8 * s);
+            for (int s = 0; s < 2; ++s) {
+                fa[s] = *(const f32x4 *)(As + lrow * LDT + koff + 8 * s);
+                fr[s] = *(const f32x4 *)(Ws + (0 * CN + lrow) * LDT + koff + 8 * s);
+                fz[s] = *(const f32x4 *)(Ws + (1 * CN + lrow) * LDT + koff + 8 * s);
+                fn[s] = *(const f32x4 *)(Ws + (2 * CN + lrow) * LDT + koff + 8 * s);
+            }
+        };
+        auto mfma_chunk = [&](int c, const f32x4 (&fa)[2], const f32x4 (&fr)[2],
+                              const f32x4 (&fz)[2], const f32x4 (&fn)[2]) {
+            if (c < a.nx_chunks) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            fa[s][e], fr[s][e], acc_r, 0, 0, 0);
+                        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            fa[s][e], fz[s][e], acc_z, 0, 0, 0);
+                        acc_ni = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            fa[s][e], fn[s][e], acc_ni, 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            fa[s][e], fr[s][e], acc_r, 0, 0, 0);
+                        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            fa[s][e], fz[s][e], acc_z, 0, 0, 0);
+                        acc_nh = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            fa[s][e], fn[s][e], acc_nh, 0, 0, 0);
+                    }
+            }
+        };
+        __syncthreads();  // barrier #0
+        read_frags(0, fa0, fr0, fz0, fn0);
+        int stage = 1;    // stage of chunk c + 1
+        for (int c = 0; c < npad; c += 2) {
+            read_frags(stage, fa1, fr1, fz1, fn1);   // prefetch chunk c + 1
+            if (c < nchunks) mfma_chunk(c, fa0, fr0, fz0, fn0);
+            stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+            __syncthreads();
+            read_frags(stage, fa0, fr0, fz0, fn0);   // prefetch chunk c + 2
+            if (c + 1 < nchunks) mfma_chunk(c + 1, fa1, fr1, fz1, fn1);
+            stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+            __syncthreads();
         }
-        if (c < a.nx_chunks) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                        fa[s][e], fr[s][e], acc_r, 0, 0, 0);
-                    acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                        fa[s][e], fz[s][e], acc_z, 0, 0, 0);
-                    acc_ni = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                        fa[s][e], fn[s][e], acc_ni, 0, 0, 0);
-                }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                        fa[s][e], fr[s][e], acc_r, 0, 0, 0);
-                    acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                        fa[s][e], fz[s][e], acc_z, 0, 0, 0);
-                    acc_nh = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                        fa[s][e], fn[s][e], acc_nh, 0, 0, 0);
-                }
-        }
-    };
-
-    // Loads are issued unconditionally (the tail re-reads the last chunk) so
-    // the loop body is straight-line and hipcc emits exact vmcnt(N) waits: the
-    // set being stored only waits for its own, older loads.
-    const int last = nchunks - 1;
-    load_chunk(0, ra0, rw0);
-    load_chunk(min(1, last), ra1, rw1);
-    const int npairs = nchunks >> 1;
-    for (int p = 0; p < npairs; ++p) {
-        const int c = 2 * p;
-        store_chunk(0, ra0, rw0);
-        __syncthreads();
-        load_chunk(min(c + 2, last), ra0, rw0);
-        compute(0, c);
-        store_chunk(1, ra1, rw1);
-        __syncthreads();
-        load_chunk(min(c + 3, last), ra1, rw1);
-        compute(1, c + 1);
-    }
-    if (nchunks & 1) {
-        store_chunk(0, ra0, rw0);
-        __syncthreads();
-        compute(0, last);
     }
 
     // cross-wave reduction of the 4 partial tiles through LDS
     __syncthreads();
     float *red = lds;  // [wave][tile][32][32]
+    if (wave < 4) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        float *base = red + (wave * 4) * 1024 + row * 32 + lrow;
-        base[0 * 1024] = acc_r[r];
-        base[1 * 1024] = acc_z[r];
-        base[2 * 1024] = acc_ni[r];
-        base[3 * 1024] = acc_nh[r];
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float *base = red + (wave * 4) * 1024 + row * 32 + lrow;
+            base[0 * 1024] = acc_r[r];
+            base[1 * 1024] = acc_z[r];
+            base[2 * 1024] = acc_ni[r];
+            base[3 * 1024] = acc_nh[r];
+        }
     }
     __syncthreads();
 
     const int H = a.H, Hn = a.Hn;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = tid + 256 * q;
+    for (int q = 0; q < 2; ++q) {
+        const int e = tid + 512 * q;
         const int row = e >> 5, col = e & 31;
         const int b = b0 + row, j = j0 + col;
         float s[4];
@@ -490,7 +521,7 @@ int grid_for(long long n) {
 
 int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
     dim3 grid(a.Hn / CN, (a.B + CM - 1) / CM);
-    hipLaunchKernelGGL(gru_cell_fwd_kernel, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(gru_cell_fwd_kernel, grid, dim3(512), 0, stream, a);
     return 0;
 }
 
