@@ -71,6 +71,50 @@ void pcm_probe_end_(int id, hipStream_t st) {
     g_probe_used += 2;
 }
 
+// ---- side stream for the time-parallel weight gradients ---------------------------
+// The reverse recurrence is a chain of short, latency-bound launches; the
+// weight-gradient GEMMs of steps the chain has already passed run beside it on
+// a second stream (created once per device, never destroyed).
+#include <stdlib.h>
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    int next = 0;
+    bool ok = false;
+};
+static SideStream g_side[16];
+
+static SideStream *side_stream() {
+    static const bool disabled = getenv("PCM_NO_OVERLAP") != nullptr;
+    if (disabled) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideStream &s = g_side[dev];
+    if (!s.ok) {
+        // lowest priority: the latency-critical chain on the caller's stream
+        // is dispatched first whenever both have work
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking,
+                                        least) != hipSuccess)
+            return nullptr;
+        for (int i = 0; i < 8; ++i)
+            if (hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) !=
+                hipSuccess)
+                return nullptr;
+        s.ok = true;
+    }
+    return &s;
+}
+
+// make `waiter` wait for everything enqueued on `signal` so far
+static void stream_wait(SideStream *s, hipStream_t signal, hipStream_t waiter) {
+    hipEvent_t e = s->ev[s->next];
+    s->next = (s->next + 1) & 7;
+    (void)hipEventRecord(e, signal);
+    (void)hipStreamWaitEvent(waiter, e, 0);
+}
+
 // ---- layouts ----------------------------------------------------------------------
 static size_t take(size_t &off, size_t n) {
     size_t at = off;
@@ -152,6 +196,7 @@ int pcm_sg_scratch(const SGLayout &lay, SGScratch *o) {
         o->off_wpackT[l] =
             take(off, (size_t)(lay.H + lay.Kxp[l]) * 3 * lay.H);
     o->off_gemm = take(off, GEMM_SCRATCH_FLOATS);
+    o->off_gemm2 = take(off, GEMM_SCRATCH_FLOATS);
     o->gemm_bytes = GEMM_SCRATCH_FLOATS * sizeof(float);
     o->total = off;
     return PCM_OK;
@@ -482,6 +527,167 @@ int pcm_stackgru_backward(const pcm_dims *dims,
         }
     }
 
+    // ---- time-parallel parameter gradients, in chunks of steps ---------------------
+    // Rows [t_lo*B, t_hi*B) of the gate-gradient / activation buffers are final
+    // once the chain has passed step t_lo, so their products are accumulated
+    // on the side stream while the chain keeps walking down.
+    SideStream *side = side_stream();
+    hipStream_t gst = side ? side->stream : st;
+    void *gs2 = side ? (void *)(scf + sc.off_gemm2) : gs;
+    const int acc = accumulate ? 1 : 0;
+    const int nchunk = T < 5 ? T : 5;
+    const int chunk_steps = (T + nchunk - 1) / nchunk;
+    int pending_hi = T;      // steps [?, pending_hi) not yet handed to gst
+    bool first_chunk = true;
+    if (side) stream_wait(side, st, gst);  // inputs of this call are ready
+    auto param_grads = [&](int t_lo, int t_hi, bool first, bool last) -> int {
+        const size_t r0 = (size_t)t_lo * B;
+        const int R = (t_hi - t_lo) * B;
+        const int cacc = first ? acc : 1;
+        int r;
+        GemmBatch gb;
+        gb.count = 0;
+        auto flush = [&]() -> int {
+            if (gb.count == 0) return PCM_OK;
+            int q = pcm_gemm_launch(gb, gs2, gsb, gst);
+            gb.count = 0;
+            return q;
+        };
+        auto push = [&](GemmProb p) -> int {
+            p.accumulate = cacc;
+            gb.p[gb.count++] = p;
+            if (gb.count == PCM_GEMM_MAX_PROBS) return flush();
+            return PCM_OK;
+        };
+        // large, square-ish products first (share the 128x128 configuration)
+        for (int l = 0; l < L; ++l) {
+            const float *G = sv + lay.off_gates[l] + r0 * 4 * H;
+            const float *hprev = sv + lay.off_hs[l] + r0 * Hp;
+            if (grads->w_hh[l]) {
+                r = push(pcm_gemm_prob(G, 1, 4LL * H, hprev, Hp, 1,
+                                       grads->w_hh[l], H, 2 * H, H, R));
+                if (r) return r;
+                r = push(pcm_gemm_prob(G + 3 * H, 1, 4LL * H, hprev, Hp, 1,
+                                       grads->w_hh[l] + (size_t)2 * H * H, H, H,
+                                       H, R));
+                if (r) return r;
+            }
+            if (l > 0 && grads->w_ih[l]) {
+                const float *x =
+                    (drop ? sv + lay.off_xdrop[l]
+                          : sv + lay.off_hs[l - 1] + lay.hs_step()) + r0 * Hp;
+                r = push(pcm_gemm_prob(G, 1, 4LL * H, x, Hp, 1, grads->w_ih[l],
+                                       H, 3 * H, H, R));
+                if (r) return r;
+            }
+        }
+        r = flush();
+        if (r) return r;
+        // skinny products
+        const float *G0 = sv + lay.off_gates[0] + r0 * 4 * H;
+        if (grads->w_ih[0] && lay.use_stack) {
+            r = push(pcm_gemm_prob(G0, 1, 4LL * H,
+                                   sv + lay.off_xtop + r0 * lay.Wp, lay.Wp, 1,
+                                   grads->w_ih[0] + lay.E, ld0, 3 * H, lay.W, R));
+            if (r) return r;
+        }
+        if (lay.use_stack) {
+            const float *dav = sv + lay.off_av + r0 * lay.AVW;
+            const float *htop = sv + lay.off_hs[L - 1] + r0 * Hp;
+            if (grads->ctrl_w) {
+                r = push(pcm_gemm_prob(dav, 1, lay.AVW, htop, Hp, 1,
+                                       grads->ctrl_w, H, 3, H, R));
+                if (r) return r;
+            }
+            if (grads->push_w) {
+                r = push(pcm_gemm_prob(dav + 3, 1, lay.AVW, htop, Hp, 1,
+                                       grads->push_w, H, lay.W, H, R));
+                if (r) return r;
+            }
+        }
+        r = flush();
+        if (r) return r;
+        // token path: dtokg (+)= onehot^T . dGi0; at the end dW_ih0[:, :E], dEmb
+        if (grads->w_ih[0] || grads->emb) {
+            float *onehot = scf + sc.off_onehot;
+            float *dtokg = scf + sc.off_dtokg;
+            pcm_launch_onehot(tokens + r0, (long long)R, lay.V, onehot, gst);
+            GemmBatch g1;
+            g1.count = 1;
+            g1.p[0] = pcm_gemm_prob(onehot, 1, lay.V, G0, 4LL * H, 1, dtokg,
+                                    3LL * H, lay.V, 3 * H, R);
+            g1.p[0].accumulate = first ? 0 : 1;
+            r = pcm_gemm_launch(g1, gs2, gsb, gst);
+            if (r) return r;
+            if (last) {
+                GemmBatch g2;
+                g2.count = 0;
+                if (grads->w_ih[0]) {
+                    GemmProb p = pcm_gemm_prob(dtokg, 1, 3LL * H, weights->emb,
+                                               lay.E, 1, grads->w_ih[0], ld0,
+                                               3 * H, lay.E, lay.V);
+                    p.accumulate = acc;
+                    g2.p[g2.count++] = p;
+                }
+                if (grads->emb) {
+                    GemmProb p = pcm_gemm_prob(dtokg, 3LL * H, 1,
+                                               weights->w_ih[0], ld0, 1,
+                                               grads->emb, lay.E, lay.V, lay.E,
+                                               3 * H);
+                    p.accumulate = acc;
+                    g2.p[g2.count++] = p;
+                }
+                r = pcm_gemm_launch(g2, gs2, gsb, gst);
+                if (r) return r;
+            }
+        }
+        // biases: column sums of the gate gradients
+        for (int l = 0; l < L; ++l) {
+            const float *G = sv + lay.off_gates[l] + r0 * 4 * H;
+            if (grads->b_ih[l]) {
+                r = pcm_colsum_launch(G, 4LL * H, R, 3 * H, grads->b_ih[l],
+                                      nullptr, cacc, gs2, gsb, gst);
+                if (r) return r;
+            }
+            if (grads->b_hh[l]) {
+                r = pcm_colsum_launch(G, 4LL * H, R, 2 * H, grads->b_hh[l],
+                                      nullptr, cacc, gs2, gsb, gst);
+                if (r) return r;
+                r = pcm_colsum_launch(G + 3 * H, 4LL * H, R, H,
+                                      grads->b_hh[l] + 2 * H, nullptr, cacc, gs2,
+                                      gsb, gst);
+                if (r) return r;
+            }
+        }
+        if (lay.use_stack) {
+            const float *dav = sv + lay.off_av + r0 * lay.AVW;
+            if (grads->ctrl_b) {
+                r = pcm_colsum_launch(dav, lay.AVW, R, 3, grads->ctrl_b, nullptr,
+                                      cacc, gs2, gsb, gst);
+                if (r) return r;
+            }
+            if (grads->push_b) {
+                r = pcm_colsum_launch(dav + 3, lay.AVW, R, lay.W, grads->push_b,
+                                      nullptr, cacc, gs2, gsb, gst);
+                if (r) return r;
+            }
+        }
+        return PCM_OK;
+    };
+    // hand steps [t_lo, pending_hi) to the gradient stream
+    auto flush_param_grads = [&](int t_lo) -> int {
+        if (t_lo >= pending_hi) return PCM_OK;
+        if (side) stream_wait(side, st, gst);
+        // beside the chain: pad the GEMM blocks' LDS so that at most two of
+        // them share a CU with a chain block (52 KiB) and it always fits
+        g_pcm_gemm_lds_pad = side ? 4096 : 0;
+        int r = param_grads(t_lo, pending_hi, first_chunk, t_lo == 0);
+        g_pcm_gemm_lds_pad = 0;
+        first_chunk = false;
+        pending_hi = t_lo;
+        return r;
+    };
+
     for (int t = T - 1; t >= 0; --t) {
         for (int l = L - 1; l >= 0; --l) {
             float *gates = sv + lay.off_gates[l] + (size_t)t * B * 4 * H;
@@ -601,6 +807,12 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             pcm_probe_end(PCM_K_STACK_BWD, st);
             cur ^= 1;
         }
+        // the control gradients of step t feed the gate kernel of step t-1
+        // only as a READ, so rows >= t are final here
+        if (t > 0 && (T - t) % chunk_steps == 0) {
+            rc = flush_param_grads(t);
+            if (rc) return rc;
+        }
     }
     if (lay.use_stack) {
         // the control path of step 0 reaches the initial top-layer hidden
@@ -620,133 +832,10 @@ int pcm_stackgru_backward(const pcm_dims *dims,
     if (d_stack0 && lay.use_stack)
         pcm_launch_copy_rows(dS[cur], lay.DW, d_stack0, lay.DW, B, lay.DW, st);
 
-    // ---- time-parallel parameter gradients (K = T*B rows) -------------------------
-    const int R = T * B;
-    const int acc = accumulate ? 1 : 0;
-    {
-        GemmBatch gb;
-        gb.count = 0;
-        auto flush = [&]() -> int {
-            if (gb.count == 0) return PCM_OK;
-            int r = pcm_gemm_launch(gb, gs, gsb, st);
-            gb.count = 0;
-            return r;
-        };
-        auto push = [&](GemmProb p) -> int {
-            p.accumulate = acc;
-            gb.p[gb.count++] = p;
-            if (gb.count == PCM_GEMM_MAX_PROBS) return flush();
-            return PCM_OK;
-        };
-        // large, square-ish products first (share the 128x128 configuration)
-        for (int l = 0; l < L; ++l) {
-            const float *G = sv + lay.off_gates[l];
-            const float *hprev = sv + lay.off_hs[l];  // rows t*B+b, t < T
-            if (grads->w_hh[l]) {
-                rc = push(pcm_gemm_prob(G, 1, 4LL * H, hprev, Hp, 1,
-                                        grads->w_hh[l], H, 2 * H, H, R));
-                if (rc) return rc;
-                rc = push(pcm_gemm_prob(G + 3 * H, 1, 4LL * H, hprev, Hp, 1,
-                                        grads->w_hh[l] + (size_t)2 * H * H, H, H,
-                                        H, R));
-                if (rc) return rc;
-            }
-            if (l > 0 && grads->w_ih[l]) {
-                const float *x = drop ? sv + lay.off_xdrop[l]
-                                      : sv + lay.off_hs[l - 1] + lay.hs_step();
-                rc = push(pcm_gemm_prob(G, 1, 4LL * H, x, Hp, 1, grads->w_ih[l],
-                                        H, 3 * H, H, R));
-                if (rc) return rc;
-            }
-        }
-        rc = flush();
-        if (rc) return rc;
-        // skinny products
-        const float *G0 = sv + lay.off_gates[0];
-        if (grads->w_ih[0] && lay.use_stack) {
-            rc = push(pcm_gemm_prob(G0, 1, 4LL * H, sv + lay.off_xtop, lay.Wp, 1,
-                                    grads->w_ih[0] + lay.E, ld0, 3 * H, lay.W,
-                                    R));
-            if (rc) return rc;
-        }
-        if (lay.use_stack) {
-            const float *dav = sv + lay.off_av;
-            const float *htop = sv + lay.off_hs[L - 1];
-            if (grads->ctrl_w) {
-                rc = push(pcm_gemm_prob(dav, 1, lay.AVW, htop, Hp, 1,
-                                        grads->ctrl_w, H, 3, H, R));
-                if (rc) return rc;
-            }
-            if (grads->push_w) {
-                rc = push(pcm_gemm_prob(dav + 3, 1, lay.AVW, htop, Hp, 1,
-                                        grads->push_w, H, lay.W, H, R));
-                if (rc) return rc;
-            }
-        }
-        rc = flush();
-        if (rc) return rc;
-        // token path: dtokg = onehot^T . dGi0, then dW_ih0[:, :E] and dEmb
-        if (grads->w_ih[0] || grads->emb) {
-            float *onehot = scf + sc.off_onehot;
-            float *dtokg = scf + sc.off_dtokg;
-            pcm_launch_onehot(tokens, (long long)R, lay.V, onehot, st);
-            GemmBatch g1;
-            g1.count = 1;
-            g1.p[0] = pcm_gemm_prob(onehot, 1, lay.V, G0, 4LL * H, 1, dtokg,
-                                    3LL * H, lay.V, 3 * H, R);
-            rc = pcm_gemm_launch(g1, gs, gsb, st);
-            if (rc) return rc;
-            GemmBatch g2;
-            g2.count = 0;
-            if (grads->w_ih[0]) {
-                GemmProb p = pcm_gemm_prob(dtokg, 1, 3LL * H, weights->emb, lay.E,
-                                           1, grads->w_ih[0], ld0, 3 * H, lay.E,
-                                           lay.V);
-                p.accumulate = acc;
-                g2.p[g2.count++] = p;
-            }
-            if (grads->emb) {
-                GemmProb p = pcm_gemm_prob(dtokg, 3LL * H, 1, weights->w_ih[0],
-                                           ld0, 1, grads->emb, lay.E, lay.V,
-                                           lay.E, 3 * H);
-                p.accumulate = acc;
-                g2.p[g2.count++] = p;
-            }
-            rc = pcm_gemm_launch(g2, gs, gsb, st);
-            if (rc) return rc;
-        }
-        // biases: column sums of the gate gradients
-        for (int l = 0; l < L; ++l) {
-            const float *G = sv + lay.off_gates[l];
-            if (grads->b_ih[l]) {
-                rc = pcm_colsum_launch(G, 4LL * H, R, 3 * H, grads->b_ih[l],
-                                       nullptr, acc, gs, gsb, st);
-                if (rc) return rc;
-            }
-            if (grads->b_hh[l]) {
-                rc = pcm_colsum_launch(G, 4LL * H, R, 2 * H, grads->b_hh[l],
-                                       nullptr, acc, gs, gsb, st);
-                if (rc) return rc;
-                rc = pcm_colsum_launch(G + 3 * H, 4LL * H, R, H,
-                                       grads->b_hh[l] + 2 * H, nullptr, acc, gs,
-                                       gsb, st);
-                if (rc) return rc;
-            }
-        }
-        if (lay.use_stack) {
-            const float *dav = sv + lay.off_av;
-            if (grads->ctrl_b) {
-                rc = pcm_colsum_launch(dav, lay.AVW, R, 3, grads->ctrl_b,
-                                       nullptr, acc, gs, gsb, st);
-                if (rc) return rc;
-            }
-            if (grads->push_b) {
-                rc = pcm_colsum_launch(dav + 3, lay.AVW, R, lay.W, grads->push_b,
-                                       nullptr, acc, gs, gsb, st);
-                if (rc) return rc;
-            }
-        }
-    }
+    // the remaining chunk(s) and the join with the side stream
+    rc = flush_param_grads(0);
+    if (rc) return rc;
+    if (side) stream_wait(side, gst, st);
     return pcm_check_launch("stackgru_backward");
 }
 

@@ -57,6 +57,8 @@ size_t pcm_gemm_scratch_bytes(const GemmBatch &batch);
 int pcm_gemm_launch(const GemmBatch &batch, void *scratch,
                     size_t scratch_bytes, hipStream_t stream);
 
+extern int g_pcm_gemm_lds_pad;
+
 static inline GemmProb pcm_gemm_prob(const float *A, long long a_rs,
                                      long long a_cs, const float *B,
                                      long long b_rs, long long b_cs, float *C,

@@ -227,6 +227,8 @@ size_t pcm_gemm_scratch_bytes(const GemmBatch &batch) {
     return total * sizeof(float);
 }
 
+int g_pcm_gemm_lds_pad = 0;  // extra dynamic LDS per block (caps blocks per CU)
+
 int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
                     hipStream_t stream) {
     PCM_REQUIRE(batch.count >= 1 && batch.count <= PCM_GEMM_MAX_PROBS,
@@ -257,10 +259,12 @@ int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
     dim3 grid(pl.gx, pl.gy, batch.count * pl.splits);
     float *slab = (float *)scratch;
     if (pl.big)
-        hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), 0, stream,
+        hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), g_pcm_gemm_lds_pad,
+                           stream,
                            batch, pl.splits, slab, slabs);
     else
-        hipLaunchKernelGGL((gemm_kernel<1, 1>), grid, dim3(256), 0, stream,
+        hipLaunchKernelGGL((gemm_kernel<1, 1>), grid, dim3(256), g_pcm_gemm_lds_pad,
+                           stream,
                            batch, pl.splits, slab, slabs);
     if (pl.splits > 1) {
         long long maxel = 0;
@@ -277,15 +281,33 @@ int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
 namespace {
 constexpr int CS_ROWS = 256;  // rows per partial block
 
+// block: 64 columns x 4 row groups; every thread sums 64 rows of its column
+// (coalesced 256-B row segments, 8 independent loads in flight), then the 4
+// row groups are combined through LDS in a fixed order.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(
     const float *X, long long ldx, int M, int N, float *partial) {
-    // block (bx, by): columns bx*256 + tid, rows by*CS_ROWS ...
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    const int r0 = blockIdx.y * CS_ROWS, r1 = min(M, r0 + CS_ROWS);
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + col;
+    const int r0 = blockIdx.y * CS_ROWS + grp * (CS_ROWS / 4);
+    const int r1 = min(M, r0 + CS_ROWS / 4);
     float s = 0.0f;
-    for (int r = r0; r < r1; ++r) s += X[(long long)r * ldx + n];
-    partial[(long long)blockIdx.y * N + n] = s;
+    if (n < N) {
+        int r = r0;
+        for (; r + 8 <= r1; r += 8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = X[(long long)(r + i) * ldx + n];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+        }
+        for (; r < r1; ++r) s += X[(long long)r * ldx + n];
+    }
+    red[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && n < N)
+        partial[(long long)blockIdx.y * N + n] =
+            ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
 }
 
 __global__ __launch_bounds__(256) void colsum_final_kernel(
@@ -314,7 +336,7 @@ int pcm_colsum_launch(const float *X, long long ldx, int M, int N, float *out,
     PCM_REQUIRE(scratch && scratch_bytes >= pcm_colsum_scratch_bytes(M, N),
                 PCM_ENOMEM, "colsum: scratch too small");
     const int parts = (M + CS_ROWS - 1) / CS_ROWS;
-    dim3 g1((N + 255) / 256, parts);
+    dim3 g1((N + 63) / 64, parts);
     hipLaunchKernelGGL(colsum_partial_kernel, g1, dim3(256), 0, stream, X, ldx,
                        M, N, (float *)scratch);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0,

@@ -49,7 +49,8 @@ struct SGScratch {
     size_t off_dtokg;   // V x 3H   gradient of the token gate table
     size_t off_tmp;     // 3H x E   scratch product
     size_t off_wpackT[PCM_MAX_LAYERS];  // (H + Kxp) x 3H transposed weights
-    size_t off_gemm;    // split-K slabs / column-sum partials
+    size_t off_gemm;    // split-K slabs / column-sum partials (main stream)
+    size_t off_gemm2;   // same for the weight-gradient side stream
     size_t gemm_bytes;
     size_t total;       // floats
 };
@@ -130,6 +131,7 @@ struct CellBwdArgs {
     float *dx;            // [B, ldx] += (l > 0: dh of the layer below) or = (dtop)
     int ldx, dx_accumulate, dx_cols;
     int B, H, Hp, NT;     // NT = H + Kxp rows of wpackT
+    int reg_cols, reg_rows;  // tile region per XCD (set by the launcher)
     int t, layer;
     float drop_p, inv_keep;  // drop_p > 0: mask dx with the forward's dropout
     uint64_t seed;

@@ -226,8 +226,17 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(CellBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[BCELL_LDS];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int n0 = blockIdx.x * BCN;   // first output column (row of wpackT)
-    const int b0 = blockIdx.y * BCM;
+    // XCD-aware tile map: blocks are dealt round-robin over the 8 XCDs, so
+    // blockIdx % 8 names the blocks that share an L2.  Each XCD gets one
+    // rectangular region of the tile grid (1/4 of the column tiles x 1/2 of
+    // the batch tiles): its weight rows plus dgates rows fit the 4 MiB L2.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int sc_ = slot % a.reg_cols, sr_ = slot / a.reg_cols;
+    const int ct = (xcd & 3) * a.reg_cols + sc_;          // column tile
+    const int bt = (xcd >> 2) * a.reg_rows + sr_;         // batch tile
+    if (ct >= a.NT / BCN || bt * BCM >= a.B) return;
+    const int n0 = ct * BCN;   // first output column (row of wpackT)
+    const int b0 = bt * BCM;
     const int H = a.H, K3 = 3 * H;
     const bool hidden_side = n0 < H;   // tile of dh[l] (uses dnh) or of dx (dni)
     const int nchunks = K3 / BCK;
@@ -431,8 +440,12 @@ int pcm_launch_gate_bwd(const GateBwdArgs &a, hipStream_t stream) {
 }
 
 int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream) {
-    dim3 grid(a.NT / BCN, (a.B + BCM - 1) / BCM);
-    hipLaunchKernelGGL(gru_cell_bwd_kernel, grid, dim3(256), 0, stream, a);
+    const int nct = a.NT / BCN, nbt = (a.B + BCM - 1) / BCM;
+    CellBwdArgs b = a;
+    b.reg_cols = (nct + 3) / 4;
+    b.reg_rows = (nbt + 1) / 2;
+    dim3 grid(8 * b.reg_cols * b.reg_rows);
+    hipLaunchKernelGGL(gru_cell_bwd_kernel, grid, dim3(256), 0, stream, b);
     return 0;
 }
 
