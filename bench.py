@@ -8,10 +8,13 @@ batches -- BASELINE.json configs[1]: batch 512 per GPU, seq len 120, vocab 60
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (see the field notes in DESIGN.md section
-"Measurement").  `roofline` is for the dominant kernel (the fused GRU cell of
-the forward recurrence), its duration measured live with HIP events on the
-launch stream during the timed steps; `cpu_baseline` times the CPU oracle
-(oracle/stackgru_oracle.py, kind "port") on a bounded sample on rank 0.
+"Measurement").  `roofline` is for the dominant kernel (by summed time: the
+fused GRU cell of the reverse recurrence, `--probe 5`; `--probe 1` is the
+forward cell), its duration measured live with HIP events on the launch stream
+during the timed steps; `roofline.traffic` is the HBM-side byte count per launch
+from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json), not a live
+measurement; `cpu_baseline` times the CPU oracle (oracle/stackgru_oracle.py,
+kind "port") on a bounded sample on rank 0.
 """
 import argparse
 import ctypes
@@ -47,8 +50,9 @@ def parse():
                     help='sequences per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=128)
-    ap.add_argument('--probe', type=int, default=1,
-                    help='kernel id for the roofline probe (1 = fused cell)')
+    ap.add_argument('--probe', type=int, default=5,
+                    help='kernel id for the roofline probe (5 = reverse fused '
+                         'cell, 1 = forward fused cell, 0 = off)')
     return ap.parse_args()
 
 
@@ -60,6 +64,21 @@ def cell_flops_per_launch(p, batch):
     per_seq = [2 * 3 * hid * (width + hid)] + \
         [2 * 3 * hid * 2 * hid] * (layers - 1)
     return batch * sum(per_seq) / layers
+
+
+PROBE_KERNELS = {1: 'gru_cell_fwd_kernel', 5: 'gru_cell_bwd_kernel'}
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes
+    (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus
+    WRITE_SIZE); None when no pass has been recorded."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f)['kernels'][kernel]['bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(p, cpu_batch):
@@ -160,8 +179,10 @@ def main():
     barrier()
     cells_per_step = 2 * SEQ_LEN * p['n_layers']
     if args.probe:
-        _lib.check(lib.pcm_probe_enable(
-            args.probe, cells_per_step * args.steps * 2 + 16), 'probe')
+        # the event brackets cost ~8 % when every launch carries them, so
+        # only the launches of the FIRST timed step are bracketed (the probe
+        # stops recording once its event budget is used)
+        _lib.check(lib.pcm_probe_enable(args.probe, cells_per_step), 'probe')
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -180,21 +201,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     final_loss = float(loss.item())
+    # what an empty HIP-event bracket reads on this stream (marker cost that
+    # every probed duration carries on top of the kernel itself)
+    pairs = [(torch.cuda.Event(enable_timing=True),
+              torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+    for e0, e1 in pairs:
+        e0.record()
+        e1.record()
+    torch.cuda.synchronize()
+    empty_us = sum(e0.elapsed_time(e1) for e0, e1 in pairs) / len(pairs) * 1e3
     assert final_loss == final_loss, 'loss is NaN'
 
     if rank == 0:
         tokens_per_step = world * args.batch * SEQ_LEN
         value = tokens_per_step * args.steps / elapsed
         roofline = None
-        if args.probe == 1 and probe_n.value > 0:
-            avg_s = probe_ms.value / probe_n.value * 1e-3
+        if args.probe in PROBE_KERNELS and probe_n.value > 0:
+            # a bracket reads the kernel plus the cost of its two event
+            # markers; the empty bracket measured above is taken off so the
+            # figure is the launch duration rocprofv3 reports
+            raw_s = probe_ms.value / probe_n.value * 1e-3
+            avg_s = max(raw_s - empty_us * 1e-6, 1e-9)
             achieved = cell_flops_per_launch(p, args.batch) / avg_s / 1e12
             roofline = {
-                'bound': 'mfma', 'kernel': 'gru_cell_fwd_kernel',
+                'bound': 'mfma', 'kernel': PROBE_KERNELS[args.probe],
                 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
                 'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
-                'traffic': None,
+                'traffic': pmc_traffic(PROBE_KERNELS[args.probe]),
                 'avg_launch_us': avg_s * 1e6, 'launches': probe_n.value,
+                'bracket_us': raw_s * 1e6, 'empty_bracket_us': empty_us,
+                'sample': 'HIP-event brackets on every launch of the first '
+                          'timed step, minus the empty-bracket reading',
             }
         cpu = None
         if not args.no_cpu_baseline:

@@ -82,8 +82,10 @@ int pcm_device_check(void);
  * hipEvents on its own stream.  pcm_probe_read synchronises on the recorded
  * events and returns the summed duration and launch count since enable.
  * Ids: 1 fused GRU cell (forward), 2 stack step (forward), 3 gate gradient,
- * 4 stack step (backward), 5 per-step dgates.W GEMM group (backward, includes
- * its split-K reduce); 0 disables.  Not thread safe; one device per process.
+ * 4 stack step (backward), 5 fused reverse GRU cell (the dgates.W products of
+ * one layer-step; the generic GEMM group and its split-K reduce when the hidden
+ * size is not a multiple of 64); 0 disables.  Not thread safe; one device per
+ * process.
  */
 int pcm_probe_enable(int32_t kernel_id, int32_t max_launches);
 int pcm_probe_read(double *total_ms, int64_t *launches, int64_t *dropped);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts_pmc.sh <tag> <counters...>
+# usage: tools/pmc.sh <tag> <counters...>
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc_$tag

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts_prof.sh <tag>   (runs on the GPU box: tests, then a profiled bench)
+# usage: tools/prof.sh <tag>   (runs on the GPU box: tests, then a profiled bench)
 tag=$1
 mkdir -p gpurun_out
 timeout -k 10 600 python -u -m pytest tests/test_gpu_parity.py -x -q --timeout 300 --timeout-method thread > gpurun_out/t_$tag.log 2>&1
