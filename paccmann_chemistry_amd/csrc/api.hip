@@ -192,6 +192,8 @@ int pcm_sg_scratch(const SGLayout &lay, SGScratch *o) {
     o->off_onehot = take(off, (size_t)lay.T * lay.B * lay.V);
     o->off_dtokg = take(off, (size_t)lay.V * 3 * lay.H);
     o->off_tmp = take(off, (size_t)lay.B * lay.Hp);
+    o->off_dwx = take(off, (size_t)3 * lay.H * (lay.Wp > 0 ? lay.Wp : 4));
+    o->off_dcw = take(off, (size_t)(lay.AVW > 0 ? lay.AVW : 4) * lay.H);
     for (int l = 0; l < lay.L; ++l)
         o->off_wpackT[l] =
             take(off, (size_t)(lay.H + lay.Kxp[l]) * 3 * lay.H);
@@ -583,63 +585,90 @@ int pcm_stackgru_backward(const pcm_dims *dims,
         }
         r = flush();
         if (r) return r;
-        // skinny products
+        // skinny products over the same long reduction.  When the rows allow
+        // 16-byte loads they go through padded scratch products (the stack top
+        // is stored Wp wide with zero padding, the controls AVW wide) so the
+        // K-major kernel takes them; the valid block is then added to the
+        // gradient.  Otherwise the strided generic kernel computes them in place.
         const float *G0 = sv + lay.off_gates[0] + r0 * 4 * H;
+        const bool pad_ok = (R % 16) == 0 && (H % 4) == 0;
+        float *dwx = scf + sc.off_dwx, *dcw = scf + sc.off_dcw;
+        float *onehot = scf + sc.off_onehot;
+        float *dtokg = scf + sc.off_dtokg;
+        const bool tok_path = grads->w_ih[0] || grads->emb;
+        if (tok_path)
+            pcm_launch_onehot(tokens + r0, (long long)R, lay.V, onehot, gst);
         if (grads->w_ih[0] && lay.use_stack) {
-            r = push(pcm_gemm_prob(G0, 1, 4LL * H,
-                                   sv + lay.off_xtop + r0 * lay.Wp, lay.Wp, 1,
-                                   grads->w_ih[0] + lay.E, ld0, 3 * H, lay.W, R));
-            if (r) return r;
+            GemmProb p = pad_ok
+                ? pcm_gemm_prob(G0, 1, 4LL * H, sv + lay.off_xtop + r0 * lay.Wp,
+                                lay.Wp, 1, dwx, lay.Wp, 3 * H, lay.Wp, R)
+                : pcm_gemm_prob(G0, 1, 4LL * H, sv + lay.off_xtop + r0 * lay.Wp,
+                                lay.Wp, 1, grads->w_ih[0] + lay.E, ld0, 3 * H,
+                                lay.W, R);
+            p.accumulate = pad_ok ? 0 : cacc;
+            gb.p[gb.count++] = p;
         }
-        if (lay.use_stack) {
+        if (lay.use_stack && (grads->ctrl_w || grads->push_w)) {
             const float *dav = sv + lay.off_av + r0 * lay.AVW;
             const float *htop = sv + lay.off_hs[L - 1] + r0 * Hp;
-            if (grads->ctrl_w) {
-                r = push(pcm_gemm_prob(dav, 1, lay.AVW, htop, Hp, 1,
-                                       grads->ctrl_w, H, 3, H, R));
-                if (r) return r;
+            if (pad_ok) {
+                GemmProb p = pcm_gemm_prob(dav, 1, lay.AVW, htop, Hp, 1, dcw, H,
+                                           lay.AVW, H, R);
+                gb.p[gb.count++] = p;
+            } else {
+                if (grads->ctrl_w) {
+                    GemmProb p = pcm_gemm_prob(dav, 1, lay.AVW, htop, Hp, 1,
+                                               grads->ctrl_w, H, 3, H, R);
+                    p.accumulate = cacc;
+                    gb.p[gb.count++] = p;
+                }
+                if (grads->push_w) {
+                    GemmProb p = pcm_gemm_prob(dav + 3, 1, lay.AVW, htop, Hp, 1,
+                                               grads->push_w, H, lay.W, H, R);
+                    p.accumulate = cacc;
+                    gb.p[gb.count++] = p;
+                }
             }
-            if (grads->push_w) {
-                r = push(pcm_gemm_prob(dav + 3, 1, lay.AVW, htop, Hp, 1,
-                                       grads->push_w, H, lay.W, H, R));
-                if (r) return r;
-            }
+        }
+        // token path: dtokg (+)= onehot^T . dGi0; at the end dW_ih0[:, :E], dEmb
+        if (tok_path) {
+            GemmProb p = pcm_gemm_prob(onehot, 1, lay.V, G0, 4LL * H, 1, dtokg,
+                                       3LL * H, lay.V, 3 * H, R);
+            p.accumulate = first ? 0 : 1;
+            gb.p[gb.count++] = p;
         }
         r = flush();
         if (r) return r;
-        // token path: dtokg (+)= onehot^T . dGi0; at the end dW_ih0[:, :E], dEmb
-        if (grads->w_ih[0] || grads->emb) {
-            float *onehot = scf + sc.off_onehot;
-            float *dtokg = scf + sc.off_dtokg;
-            pcm_launch_onehot(tokens + r0, (long long)R, lay.V, onehot, gst);
-            GemmBatch g1;
-            g1.count = 1;
-            g1.p[0] = pcm_gemm_prob(onehot, 1, lay.V, G0, 4LL * H, 1, dtokg,
-                                    3LL * H, lay.V, 3 * H, R);
-            g1.p[0].accumulate = first ? 0 : 1;
-            r = pcm_gemm_launch(g1, gs2, gsb, gst);
-            if (r) return r;
-            if (last) {
-                GemmBatch g2;
-                g2.count = 0;
-                if (grads->w_ih[0]) {
-                    GemmProb p = pcm_gemm_prob(dtokg, 1, 3LL * H, weights->emb,
-                                               lay.E, 1, grads->w_ih[0], ld0,
-                                               3 * H, lay.E, lay.V);
-                    p.accumulate = acc;
-                    g2.p[g2.count++] = p;
-                }
-                if (grads->emb) {
-                    GemmProb p = pcm_gemm_prob(dtokg, 3LL * H, 1,
-                                               weights->w_ih[0], ld0, 1,
-                                               grads->emb, lay.E, lay.V, lay.E,
-                                               3 * H);
-                    p.accumulate = acc;
-                    g2.p[g2.count++] = p;
-                }
-                r = pcm_gemm_launch(g2, gs2, gsb, gst);
-                if (r) return r;
+        if (pad_ok && lay.use_stack) {
+            if (grads->w_ih[0])
+                pcm_launch_add_block(dwx, lay.Wp, grads->w_ih[0] + lay.E, ld0,
+                                     3 * H, lay.W, cacc, gst);
+            if (grads->ctrl_w)
+                pcm_launch_add_block(dcw, H, grads->ctrl_w, H, 3, H, cacc, gst);
+            if (grads->push_w)
+                pcm_launch_add_block(dcw + (size_t)3 * H, H, grads->push_w, H,
+                                     lay.W, H, cacc, gst);
+        }
+        if (tok_path && last) {
+            GemmBatch g2;
+            g2.count = 0;
+            if (grads->w_ih[0]) {
+                GemmProb p = pcm_gemm_prob(dtokg, 1, 3LL * H, weights->emb,
+                                           lay.E, 1, grads->w_ih[0], ld0,
+                                           3 * H, lay.E, lay.V);
+                p.accumulate = acc;
+                g2.p[g2.count++] = p;
             }
+            if (grads->emb) {
+                GemmProb p = pcm_gemm_prob(dtokg, 3LL * H, 1,
+                                           weights->w_ih[0], ld0, 1,
+                                           grads->emb, lay.E, lay.V, lay.E,
+                                           3 * H);
+                p.accumulate = acc;
+                g2.p[g2.count++] = p;
+            }
+            r = pcm_gemm_launch(g2, gs2, gsb, gst);
+            if (r) return r;
         }
         // biases: column sums of the gate gradients
         for (int l = 0; l < L; ++l) {
@@ -678,15 +707,7 @@ int pcm_stackgru_backward(const pcm_dims *dims,
     auto flush_param_grads = [&](int t_lo) -> int {
         if (t_lo >= pending_hi) return PCM_OK;
         if (side) stream_wait(side, st, gst);
-        // beside the chain the big products run as a fixed set of resident
-        // blocks (2 per CU), so a chain block always finds LDS and wave slots
-        static const int resident = [] {
-            const char *e = getenv("PCM_DW_RESIDENT");
-            return e ? atoi(e) : 512;
-        }();
-        g_pcm_gemm_resident = side ? resident : 0;
         int r = param_grads(t_lo, pending_hi, first_chunk, t_lo == 0);
-        g_pcm_gemm_resident = 0;
         first_chunk = false;
         pending_hi = t_lo;
         return r;

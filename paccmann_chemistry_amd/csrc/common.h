@@ -58,7 +58,6 @@ int pcm_gemm_launch(const GemmBatch &batch, void *scratch,
                     size_t scratch_bytes, hipStream_t stream);
 
 extern int g_pcm_gemm_lds_pad;
-extern int g_pcm_gemm_resident;
 
 static inline GemmProb pcm_gemm_prob(const float *A, long long a_rs,
                                      long long a_cs, const float *B,

@@ -6,6 +6,7 @@
 // logits, mu/logvar, latent->hidden, all weight gradients (sum over T*B rows)
 // and, in the reverse recurrence, the per-step dgates.W products.
 #include <algorithm>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -173,33 +174,148 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmBatch batch, int splits,
     gemm_tile<TM, TN>(batch, pz, sk, m0, n0, splits, slab, slabs, As, Bs);
 }
 
-// Resident variant: a fixed, small number of blocks walks the (problem, split,
-// tile) units, so the launch never holds more than `gridDim.x` blocks' worth of
-// LDS / wave slots and the latency-bound recurrence kernels of the other
-// stream always find room on every CU beside it.
-struct UnitMap {
-    int first[PCM_GEMM_MAX_PROBS + 1];  // first unit of each problem
+// ---- K-major x K-major products (weight gradients) --------------------------------
+// C[M,N] (+)= sum_r A[r][m] * B[r][n] with both operands contiguous along their
+// output index (a_rs == 1, b_cs == 1), M and N multiples of 4, K of 16 (tiles
+// that hang over M or N re-read the last valid columns and mask the store):
+// 16-byte global loads straight into a [k][m] LDS layout whose row stride (160
+// floats) puts the two k rows a wave reads on disjoint banks; register prefetch
+// two chunks ahead, LDS double buffer, one barrier per chunk.  Blocks are dealt
+// so that an XCD (blockIdx % 8) works on its own K splits across all tiles: every
+// operand byte is fetched from HBM by one XCD only and the tiles marching
+// through the same K range share it in that XCD's L2.
+constexpr int TN_LD = 160;
+struct TileMap {
+    int first[PCM_GEMM_MAX_PROBS + 1];  // first tile of each problem
     int tiles_n[PCM_GEMM_MAX_PROBS];
-    int tiles[PCM_GEMM_MAX_PROBS];      // tiles per split
 };
 
-template <int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_resident_kernel(
-    GemmBatch batch, int splits, float *slab, SlabInfo slabs, UnitMap um) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    __shared__ float As[2 * BK * (BM + 1)];
-    __shared__ float Bs[2 * BK * (BN + 1)];
-    const int total = um.first[batch.count];
-    for (int u = blockIdx.x; u < total; u += gridDim.x) {
-        int pz = 0;
-        while (u >= um.first[pz + 1]) ++pz;
-        const int v = u - um.first[pz];
-        const int sk = v / um.tiles[pz];
-        const int tile = v - sk * um.tiles[pz];
-        const int tm = tile / um.tiles_n[pz], tn = tile - tm * um.tiles_n[pz];
-        gemm_tile<TM, TN>(batch, pz, sk, tm * BM, tn * BN, splits, slab, slabs,
-                          As, Bs);
-        __syncthreads();  // LDS is reused by the next unit
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmBatch batch,
+                                                         int splits, float *slab,
+                                                         SlabInfo slabs,
+                                                         TileMap tm) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK * TN_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * TN_LD];
+    const int ntiles = tm.first[batch.count];
+    int sk, t;
+    if ((splits & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int q = j / ntiles;
+        sk = xcd + 8 * q;
+        t = j - q * ntiles;
+    } else {
+        sk = blockIdx.x / ntiles;
+        t = blockIdx.x - sk * ntiles;
+    }
+    int pz = 0;
+    while (t >= tm.first[pz + 1]) ++pz;
+    const GemmProb &p = batch.p[pz];
+    const int tl = t - tm.first[pz];
+    const int tmi = tl / tm.tiles_n[pz];
+    const int m0 = tmi * 128, n0 = (tl - tmi * tm.tiles_n[pz]) * 128;
+
+    const int nchunks = p.K / BK;
+    const int cps = (nchunks + splits - 1) / splits;
+    const int c0 = sk * cps;
+    const int c1 = min(nchunks, c0 + cps);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lrow = lane & 31, lk = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    if (c0 < c1) {
+        // thread -> (k row, 4-wide column group) of the 16 x 128 operand chunks
+        const int k_a = tid >> 5, q_a = tid & 31;  // + 8 rows for the second load
+        const float *ga =
+            p.A + (long long)k_a * p.a_cs + min(m0 + 4 * q_a, p.M - 4);
+        const float *gb =
+            p.B + (long long)k_a * p.b_rs + min(n0 + 4 * q_a, p.N - 4);
+        const long long a8 = 8 * p.a_cs, b8 = 8 * p.b_rs;
+        const int lofs = k_a * TN_LD + 4 * q_a;
+        const int last = c1 - 1;
+        f32x4 ra[2][2], rb[2][2];
+        auto load_chunk = [&](int c, f32x4 (&qa)[2], f32x4 (&qb)[2]) {
+            c = min(c, last);  // the tail re-reads the last chunk (never stored)
+            const float *pa = ga + (long long)c * BK * p.a_cs;
+            const float *pb = gb + (long long)c * BK * p.b_rs;
+            qa[0] = *(const f32x4 *)pa;
+            qa[1] = *(const f32x4 *)(pa + a8);
+            qb[0] = *(const f32x4 *)pb;
+            qb[1] = *(const f32x4 *)(pb + b8);
+        };
+        auto store_chunk = [&](int buf, const f32x4 (&qa)[2],
+                               const f32x4 (&qb)[2]) {
+            *(f32x4 *)(&As[buf][lofs]) = qa[0];
+            *(f32x4 *)(&As[buf][lofs + 8 * TN_LD]) = qa[1];
+            *(f32x4 *)(&Bs[buf][lofs]) = qb[0];
+            *(f32x4 *)(&Bs[buf][lofs + 8 * TN_LD]) = qb[1];
+        };
+        auto compute = [&](int buf) {
+            const float *as = &As[buf][lk * TN_LD + wm * 64 + lrow];
+            const float *bs = &Bs[buf][lk * TN_LD + wn * 64 + lrow];
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 2) {
+                const float a0 = as[kk * TN_LD], a1 = as[kk * TN_LD + 32];
+                const float b0 = bs[kk * TN_LD], b1 = bs[kk * TN_LD + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        };
+        load_chunk(c0, ra[0], rb[0]);
+        load_chunk(c0 + 1, ra[1], rb[1]);
+        // pairs of chunks so the register sets alternate without copies; the
+        // loads are unconditional, hence exact vmcnt waits
+        int c = c0;
+        for (; c + 1 < c1; c += 2) {
+            store_chunk(0, ra[0], rb[0]);
+            load_chunk(c + 2, ra[0], rb[0]);
+            __syncthreads();
+            compute(0);
+            store_chunk(1, ra[1], rb[1]);
+            load_chunk(c + 3, ra[1], rb[1]);
+            __syncthreads();
+            compute(1);
+        }
+        if (c < c1) {
+            store_chunk(0, ra[0], rb[0]);
+            __syncthreads();
+            compute(0);
+        }
+    }
+
+    const float alpha = p.alpha_ptr ? *p.alpha_ptr : 1.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int gn = n0 + (wn * 2 + j) * 32 + lrow;
+            if (gn >= p.N) continue;
+            const float bias = (p.bias && splits == 1) ? p.bias[gn] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) +
+                               4 * lk;
+                if (gm >= p.M) continue;
+                if (splits == 1) {
+                    float *c = p.C + (long long)gm * p.ldc + gn;
+                    float v = alpha * acc[i][j][r] + bias;
+                    if (p.accumulate) v += *c;
+                    *c = v;
+                } else {
+                    slab[slabs.off[pz] +
+                         ((long long)sk * p.M + gm) * p.N + gn] = acc[i][j][r];
+                }
+            }
+        }
     }
 }
 
@@ -231,8 +347,6 @@ struct Plan {
 
 }  // namespace
 int g_pcm_gemm_lds_pad = 0;   // extra dynamic LDS per block (caps blocks per CU)
-int g_pcm_gemm_resident = 0;  // > 0: at most this many resident blocks (128x128
-                              // tile launches only), see gemm_resident_kernel
 namespace {
 
 Plan make_plan(const GemmBatch &batch, bool allow_split) {
@@ -260,21 +374,49 @@ Plan make_plan(const GemmBatch &batch, bool allow_split) {
         splits = std::max(1, std::min(splits, 64));
         // second K segment requires chunk-aligned splits only (always true)
     }
-    if (allow_split && pl.big && g_pcm_gemm_resident > 0) {
-        // resident blocks walk the units: aim at two rounds of units
-        const int chunks = (minK + BK - 1) / BK;
-        splits = (int)((2LL * g_pcm_gemm_resident + tiles / 2) / tiles);
-        splits = std::min(splits, chunks / 16);
-        splits = std::max(1, std::min(splits, 64));
-    }
     pl.splits = splits;
     return pl;
+}
+
+// every problem K-major x K-major with whole 128 x 128 tiles and 16-byte loads?
+bool tn_eligible(const GemmBatch &batch) {
+    for (int i = 0; i < batch.count; ++i) {
+        const GemmProb &p = batch.p[i];
+        if (p.a_rs != 1 || p.b_cs != 1 || p.K1 != 0) return false;
+        if ((p.M & 3) || (p.N & 3) || (p.K & 15) || p.M < 4 || p.N < 4)
+            return false;
+        if ((p.a_cs & 3) || (p.b_rs & 3)) return false;
+        if (((uintptr_t)p.A | (uintptr_t)p.B) & 15) return false;
+    }
+    return true;
+}
+
+// skinny products over a long reduction are worth the 128 x 128 kernel too
+bool tn_long_k(const GemmBatch &batch) {
+    for (int i = 0; i < batch.count; ++i)
+        if (batch.p[i].K < 2048) return false;
+    return true;
+}
+
+int tn_splits(const GemmBatch &batch, long long tiles, int minK) {
+    static const int forced = [] {
+        const char *e = getenv("PCM_TN_SPLITS");
+        return e ? atoi(e) : 0;
+    }();
+    const int chunks = minK / BK;
+    int splits = forced > 0 ? forced : 8;
+    if (forced <= 0)
+        while (tiles * splits < 1024 && splits < 64) splits += 8;
+    while (splits > 8 && chunks / splits < 16) splits -= 8;
+    if (chunks / splits < 16) splits = std::max(1, std::min(splits, chunks / 16));
+    return splits;
 }
 
 }  // namespace
 
 size_t pcm_gemm_scratch_bytes(const GemmBatch &batch) {
     Plan pl = make_plan(batch, true);
+    if (tn_eligible(batch)) pl.splits = std::max(pl.splits, 64);
     if (pl.splits == 1) return 0;
     size_t total = 0;
     for (int i = 0; i < batch.count; ++i)
@@ -297,6 +439,24 @@ int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
                     "gemm: second K segment without operands");
     }
     Plan pl = make_plan(batch, scratch != nullptr);
+    const bool use_tn = tn_eligible(batch) && (pl.big || tn_long_k(batch));
+    TileMap tmap;
+    long long tn_tiles = 0;
+    if (use_tn) {
+        int minK = 1 << 30;
+        for (int i = 0; i < PCM_GEMM_MAX_PROBS; ++i) {
+            tmap.first[i] = (int)tn_tiles;
+            tmap.tiles_n[i] = 1;
+            if (i >= batch.count) continue;
+            tmap.tiles_n[i] = (batch.p[i].N + 127) / 128;
+            tn_tiles += (long long)((batch.p[i].M + 127) / 128) * tmap.tiles_n[i];
+            minK = std::min(minK, batch.p[i].K);
+        }
+        tmap.first[PCM_GEMM_MAX_PROBS] = (int)tn_tiles;
+        for (int i = batch.count; i <= PCM_GEMM_MAX_PROBS; ++i)
+            tmap.first[i] = (int)tn_tiles;
+        pl.splits = scratch ? tn_splits(batch, tn_tiles, minK) : 1;
+    }
     SlabInfo slabs;
     size_t need = 0;
     for (int i = 0; i < PCM_GEMM_MAX_PROBS; ++i) slabs.off[i] = 0;
@@ -311,25 +471,10 @@ int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
     }
     dim3 grid(pl.gx, pl.gy, batch.count * pl.splits);
     float *slab = (float *)scratch;
-    if (pl.big && g_pcm_gemm_resident > 0) {
-        UnitMap um;
-        int units = 0;
-        for (int i = 0; i < PCM_GEMM_MAX_PROBS; ++i) {
-            um.first[i] = units;
-            um.tiles_n[i] = um.tiles[i] = 1;
-            if (i >= batch.count) continue;
-            const GemmProb &p = batch.p[i];
-            um.tiles_n[i] = (p.N + 127) / 128;
-            um.tiles[i] = ((p.M + 127) / 128) * um.tiles_n[i];
-            units += um.tiles[i] * pl.splits;
-        }
-        um.first[PCM_GEMM_MAX_PROBS] = units;
-        for (int i = batch.count; i <= PCM_GEMM_MAX_PROBS; ++i)
-            um.first[i] = units;
-        const int blocks = std::min(units, g_pcm_gemm_resident);
-        hipLaunchKernelGGL((gemm_resident_kernel<2, 2>), dim3(blocks), dim3(256),
-                           g_pcm_gemm_lds_pad, stream, batch, pl.splits, slab,
-                           slabs, um);
+    if (use_tn) {
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(tn_tiles * pl.splits)),
+                           dim3(256), g_pcm_gemm_lds_pad, stream, batch,
+                           pl.splits, slab, slabs, tmap);
     } else if (pl.big)
         hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), g_pcm_gemm_lds_pad,
                            stream,

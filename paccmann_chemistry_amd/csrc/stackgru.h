@@ -47,7 +47,9 @@ struct SGScratch {
     size_t off_dtop;    // B x Wp
     size_t off_onehot;  // T*B x V  one-hot of the input tokens
     size_t off_dtokg;   // V x 3H   gradient of the token gate table
-    size_t off_tmp;     // 3H x E   scratch product
+    size_t off_tmp;     // B x Hp   scratch product (generic reverse path)
+    size_t off_dwx;     // 3H x Wp  gradient of W_ih0's stack-top columns (padded)
+    size_t off_dcw;     // AVW x H  gradient of [ctrl_w ; push_w] (padded rows)
     size_t off_wpackT[PCM_MAX_LAYERS];  // (H + Kxp) x 3H transposed weights
     size_t off_gemm;    // split-K slabs / column-sum partials (main stream)
     size_t off_gemm2;   // same for the weight-gradient side stream
@@ -170,3 +172,7 @@ int pcm_launch_dropout_mask_mul(float *x, long long ldx, int B, int H,
 int pcm_launch_onehot(const int64_t *tokens, long long rows, int V, float *out,
                       hipStream_t stream);
 int pcm_launch_fill(float *dst, float value, long long n, hipStream_t stream);
+// dst[r][c] (+)= src[r][c]
+int pcm_launch_add_block(const float *src, long long lds, float *dst,
+                         long long ldd, int rows, int cols, int accumulate,
+                         hipStream_t stream);

@@ -488,6 +488,23 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs a) {
     }
 }
 
+// dst[r][c] (+)= src[r][c] for a [rows, cols] block
+__global__ __launch_bounds__(256) void add_block_kernel(const float *src,
+                                                        long long lds_,
+                                                        float *dst,
+                                                        long long ldd, int rows,
+                                                        int cols,
+                                                        int accumulate) {
+    const long long total = (long long)rows * cols;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * 256) {
+        const int r = (int)(idx / cols), c = (int)(idx - (long long)r * cols);
+        const float v = src[r * lds_ + c];
+        float *d = dst + r * ldd + c;
+        *d = accumulate ? *d + v : v;
+    }
+}
+
 __global__ __launch_bounds__(256) void copy_rows_kernel(const float *src,
                                                         long long lds_,
                                                         float *dst,
@@ -549,6 +566,15 @@ int pcm_launch_copy_rows(const float *src, long long lds_, float *dst,
     hipLaunchKernelGGL(copy_rows_kernel, dim3(grid_for((long long)rows * cols)),
                        dim3(256), 0, stream, src, lds_, dst, ldd, rows, cols,
                        cols);
+    return 0;
+}
+
+int pcm_launch_add_block(const float *src, long long lds_, float *dst,
+                         long long ldd, int rows, int cols, int accumulate,
+                         hipStream_t stream) {
+    hipLaunchKernelGGL(add_block_kernel, dim3(grid_for((long long)rows * cols)),
+                       dim3(256), 0, stream, src, lds_, dst, ldd, rows, cols,
+                       accumulate);
     return 0;
 }
 
