@@ -1,0 +1,105 @@
+"""Secondary measurements of SURVEY.md section 8(d): encoder-only molecules/s
+(BASELINE.json configs[3], generate_latent_codes-style mu/logvar throughput)
+and decode molecules/s (configs[4], greedy and temperature-0.8 sampling from
+prior latents), on a bounded sample of the named workloads (the full 10 M /
+1 M sets are the same batches repeated).  One JSON line per workload.
+
+    python bench_inference.py [--batch 4096] [--batches 10]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402  (model configuration of the headline benchmark)
+
+
+def timed(fn, batches, warmup=2):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(batches):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / batches
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=4096)
+    ap.add_argument('--batches', type=int, default=10)
+    ap.add_argument('--generate-len', type=int, default=100)
+    args = ap.parse_args()
+    import paccmann_chemistry_amd as P
+    from oracle import weights as W  # synthetic inputs only
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    p = dict(bench.PARAMS, batch_size=args.batch)
+    torch.manual_seed(1234)
+    vae = P.TeacherVAE(P.StackGRUEncoder(p), P.StackGRUDecoder(p)).to(dev)
+    vae.eval()
+    seq_len, batch = bench.SEQ_LEN, args.batch
+    common = {'n_gpus': 1, 'dtype': 'f32', 'data': 'synthetic',
+              'higher_is_better': True, 'batches': args.batches}
+
+    # ---- encoder only, fixed length (padded) and ragged (packed) ----------
+    tokens = W.synthetic_tokens(seq_len, batch, p['vocab_size'], 1234).to(dev)
+    with torch.no_grad():
+        sec = timed(lambda: vae.encode(tokens), args.batches)
+    print(json.dumps(dict(
+        common, metric='encoder-only molecules/sec (mu/logvar)',
+        value=batch / sec, unit='molecules/s', ms_per_batch=sec * 1e3,
+        tokens_per_s=batch * seq_len / sec,
+        config={'workload': f'StackGRUEncoder mu/logvar, no_grad, batch '
+                            f'{batch}, seq len {seq_len}, padded'})), flush=True)
+
+    lengths = sorted(W.ragged_lengths(batch, seq_len, 4321), reverse=True)
+    ragged = W.synthetic_tokens(seq_len, batch, p['vocab_size'], 1235, lengths)
+    packed = torch.nn.utils.rnn.pack_sequence(
+        [ragged[:n, b].to(dev) for b, n in enumerate(lengths)])
+    torch.manual_seed(1234)
+    q = dict(p, batch_mode='packed')
+    vae_packed = P.TeacherVAE(P.StackGRUEncoder(q), P.StackGRUDecoder(q)).to(dev)
+    vae_packed.eval()
+    with torch.no_grad():
+        sec = timed(lambda: vae_packed.encode(packed), args.batches)
+    print(json.dumps(dict(
+        common, metric='encoder-only molecules/sec (mu/logvar)',
+        value=batch / sec, unit='molecules/s', ms_per_batch=sec * 1e3,
+        tokens_per_s=float(sum(lengths)) / sec,
+        config={'workload': f'StackGRUEncoder mu/logvar, no_grad, batch '
+                            f'{batch}, ragged lengths ~N(60,20) clipped to '
+                            f'[10,{seq_len}], packed'})), flush=True)
+
+    # ---- decode from prior latents -----------------------------------------
+    gen = torch.Generator(device='cpu').manual_seed(4321)
+    z = torch.randn(1, batch, p['latent_dim'], generator=gen).to(dev)
+    prime = torch.tensor([2], device=dev)
+    end = torch.tensor([3], device=dev)
+    for name, search in (('greedy', P.GreedySearch()),
+                         ('sampling T=0.8', P.SamplingSearch(temperature=0.8))):
+        def run():
+            return vae.decoder.generate_from_latent(
+                z, prime, end, search=search,
+                generate_len=args.generate_len, seed=99)
+        sec = timed(run, max(2, args.batches // 2))
+        print(json.dumps(dict(
+            common, metric=f'decode molecules/sec ({name})',
+            value=batch / sec, unit='molecules/s', ms_per_batch=sec * 1e3,
+            tokens_per_s=batch * args.generate_len / sec,
+            config={'workload': f'StackGRUDecoder.generate_from_latent, '
+                                f'{name}, batch {batch}, prime [2], '
+                                f'generate_len {args.generate_len}'})),
+            flush=True)
+
+
+if __name__ == '__main__':
+    main()
