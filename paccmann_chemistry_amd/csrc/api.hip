@@ -85,8 +85,13 @@ struct SideStream {
 static SideStream g_side[16];
 
 static SideStream *side_stream() {
-    static const bool disabled = getenv("PCM_NO_OVERLAP") != nullptr;
-    if (disabled) return nullptr;
+    // Off by default: with the K-major gradient kernel the products are short and
+    // MFMA-dense, and fp32 MFMA waves starve the chain's VALU phases when they
+    // share a SIMD, so running them beside the chain no longer beats one
+    // full-length launch after it (1.66 M vs 1.64 M tokens/s).  PCM_OVERLAP=1
+    // turns the side stream back on (chunk schedule: PCM_DW_CUTS).
+    static const bool enabled = getenv("PCM_OVERLAP") != nullptr;
+    if (!enabled) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     SideStream &s = g_side[dev];
@@ -193,7 +198,7 @@ int pcm_sg_scratch(const SGLayout &lay, SGScratch *o) {
     o->off_dtokg = take(off, (size_t)lay.V * 3 * lay.H);
     o->off_tmp = take(off, (size_t)lay.B * lay.Hp);
     o->off_dwx = take(off, (size_t)3 * lay.H * (lay.Wp > 0 ? lay.Wp : 4));
-    o->off_dcw = take(off, (size_t)(lay.AVW > 0 ? lay.AVW : 4) * lay.H);
+    o->off_dcw = take(off, (size_t)(lay.AVW > 0 ? lay.AVW : 4) * (lay.H + 1));
     for (int l = 0; l < lay.L; ++l)
         o->off_wpackT[l] =
             take(off, (size_t)(lay.H + lay.Kxp[l]) * 3 * lay.H);
@@ -537,8 +542,32 @@ int pcm_stackgru_backward(const pcm_dims *dims,
     hipStream_t gst = side ? side->stream : st;
     void *gs2 = side ? (void *)(scf + sc.off_gemm2) : gs;
     const int acc = accumulate ? 1 : 0;
-    const int nchunk = T < 5 ? T : 5;
-    const int chunk_steps = (T + nchunk - 1) / nchunk;
+    // Chunk boundaries (in steps already walked): shrinking chunks, so that the
+    // work still queued on the gradient stream when the chain ends is small.
+    int bounds[5];
+    int nbounds = 0;
+    {
+        static int cut_percent[5] = {100, 100, 100, 100, 100};
+        static const bool parsed = [] {
+            const char *e = getenv("PCM_DW_CUTS");  // e.g. "45,75,90,97"
+            if (!e) return true;
+            int n = 0;
+            for (const char *q = e; *q && n < 5; ++n) {
+                cut_percent[n] = atoi(q);
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+            for (; n < 5; ++n) cut_percent[n] = 100;
+            return true;
+        }();
+        (void)parsed;
+        for (int i = 0; i < 5; ++i) {
+            const int b = (int)((long long)T * cut_percent[i] / 100);
+            if (b > 0 && b < T && (nbounds == 0 || b > bounds[nbounds - 1]))
+                bounds[nbounds++] = b;
+        }
+    }
+    int next_bound = 0;
     int pending_hi = T;      // steps [?, pending_hi) not yet handed to gst
     bool first_chunk = true;
     if (side) stream_wait(side, st, gst);  // inputs of this call are ready
@@ -555,36 +584,62 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             gb.count = 0;
             return q;
         };
-        auto push = [&](GemmProb p) -> int {
-            p.accumulate = cacc;
-            gb.p[gb.count++] = p;
-            if (gb.count == PCM_GEMM_MAX_PROBS) return flush();
-            return PCM_OK;
-        };
-        // large, square-ish products first (share the 128x128 configuration)
-        for (int l = 0; l < L; ++l) {
-            const float *G = sv + lay.off_gates[l] + r0 * 4 * H;
-            const float *hprev = sv + lay.off_hs[l] + r0 * Hp;
-            if (grads->w_hh[l]) {
-                r = push(pcm_gemm_prob(G, 1, 4LL * H, hprev, Hp, 1,
-                                       grads->w_hh[l], H, 2 * H, H, R));
-                if (r) return r;
-                r = push(pcm_gemm_prob(G + 3 * H, 1, 4LL * H, hprev, Hp, 1,
-                                       grads->w_hh[l] + (size_t)2 * H * H, H, H,
-                                       H, R));
-                if (r) return r;
+        // large, square-ish products first.  Bias gradients ride along as column
+        // sums of the A operand where the K-major kernel takes the batch.
+        bool bih_done[PCM_MAX_LAYERS] = {}, bhh_done[PCM_MAX_LAYERS] = {};
+        bool cb_done = false;
+        {
+            GemmProb big[3 * PCM_MAX_LAYERS];
+            int tag[3 * PCM_MAX_LAYERS];  // layer * 2 + (0: b_hh, 1: b_ih)
+            int nbig = 0;
+            for (int l = 0; l < L; ++l) {
+                const float *G = sv + lay.off_gates[l] + r0 * 4 * H;
+                const float *hprev = sv + lay.off_hs[l] + r0 * Hp;
+                if (grads->w_hh[l]) {
+                    GemmProb p1 = pcm_gemm_prob(G, 1, 4LL * H, hprev, Hp, 1,
+                                                grads->w_hh[l], H, 2 * H, H, R);
+                    GemmProb p2 = pcm_gemm_prob(
+                        G + 3 * H, 1, 4LL * H, hprev, Hp, 1,
+                        grads->w_hh[l] + (size_t)2 * H * H, H, H, H, R);
+                    if (grads->b_hh[l]) {
+                        p1.colsum1 = grads->b_hh[l];
+                        p2.colsum1 = grads->b_hh[l] + 2 * H;
+                    }
+                    p1.accumulate = p2.accumulate = cacc;
+                    tag[nbig] = l * 2; big[nbig++] = p1;
+                    tag[nbig] = l * 2; big[nbig++] = p2;
+                }
+                if (l > 0 && grads->w_ih[l]) {
+                    const float *x =
+                        (drop ? sv + lay.off_xdrop[l]
+                              : sv + lay.off_hs[l - 1] + lay.hs_step()) + r0 * Hp;
+                    GemmProb p3 = pcm_gemm_prob(G, 1, 4LL * H, x, Hp, 1,
+                                                grads->w_ih[l], H, 3 * H, H, R);
+                    if (grads->b_ih[l]) p3.colsum1 = grads->b_ih[l];
+                    p3.accumulate = cacc;
+                    tag[nbig] = l * 2 + 1; big[nbig++] = p3;
+                }
             }
-            if (l > 0 && grads->w_ih[l]) {
-                const float *x =
-                    (drop ? sv + lay.off_xdrop[l]
-                          : sv + lay.off_hs[l - 1] + lay.hs_step()) + r0 * Hp;
-                r = push(pcm_gemm_prob(G, 1, 4LL * H, x, Hp, 1, grads->w_ih[l],
-                                       H, 3 * H, H, R));
+            // w_hh's two products of a layer stay in one batch (even count)
+            for (int i0 = 0; i0 < nbig;) {
+                int i1 = std::min(nbig, i0 + PCM_GEMM_MAX_PROBS);
+                if (i1 < nbig && tag[i1] == tag[i1 - 1] && !(tag[i1] & 1)) --i1;
+                gb.count = 0;
+                for (int i = i0; i < i1; ++i) gb.p[gb.count++] = big[i];
+                const bool takes = pcm_gemm_takes_colsum(gb, true);
+                for (int i = i0; i < i1; ++i) {
+                    if (!takes) {
+                        gb.p[i - i0].colsum1 = nullptr;
+                    } else if (big[i].colsum1) {
+                        if (tag[i] & 1) bih_done[tag[i] >> 1] = true;
+                        else bhh_done[tag[i] >> 1] = true;
+                    }
+                }
+                r = flush();
                 if (r) return r;
+                i0 = i1;
             }
         }
-        r = flush();
-        if (r) return r;
         // skinny products over the same long reduction.  When the rows allow
         // 16-byte loads they go through padded scratch products (the stack top
         // is stored Wp wide with zero padding, the controls AVW wide) so the
@@ -606,6 +661,10 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                                 lay.Wp, 1, grads->w_ih[0] + lay.E, ld0, 3 * H,
                                 lay.W, R);
             p.accumulate = pad_ok ? 0 : cacc;
+            if (pad_ok && grads->b_ih[0]) {
+                p.colsum1 = grads->b_ih[0];
+                p.cs_accumulate = cacc;
+            }
             gb.p[gb.count++] = p;
         }
         if (lay.use_stack && (grads->ctrl_w || grads->push_w)) {
@@ -614,6 +673,7 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             if (pad_ok) {
                 GemmProb p = pcm_gemm_prob(dav, 1, lay.AVW, htop, Hp, 1, dcw, H,
                                            lay.AVW, H, R);
+                p.colsum1 = dcw + (size_t)lay.AVW * H;  // [AVW] control biases
                 gb.p[gb.count++] = p;
             } else {
                 if (grads->ctrl_w) {
@@ -637,8 +697,27 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             p.accumulate = first ? 0 : 1;
             gb.p[gb.count++] = p;
         }
+        if (gb.count > 0 && pcm_gemm_takes_colsum(gb, true)) {
+            for (int i = 0; i < gb.count; ++i) {
+                if (gb.p[i].colsum1 == grads->b_ih[0] && grads->b_ih[0])
+                    bih_done[0] = true;
+                if (gb.p[i].colsum1 == dcw + (size_t)lay.AVW * H) cb_done = true;
+            }
+        } else {
+            for (int i = 0; i < gb.count; ++i)
+                gb.p[i].colsum1 = gb.p[i].colsum2 = nullptr;
+        }
         r = flush();
         if (r) return r;
+        if (cb_done) {
+            const float *dcb = dcw + (size_t)lay.AVW * H;
+            if (grads->ctrl_b)
+                pcm_launch_add_block(dcb, lay.AVW, grads->ctrl_b, 3, 1, 3, cacc,
+                                     gst);
+            if (grads->push_b)
+                pcm_launch_add_block(dcb + 3, lay.AVW, grads->push_b, lay.W, 1,
+                                     lay.W, cacc, gst);
+        }
         if (pad_ok && lay.use_stack) {
             if (grads->w_ih[0])
                 pcm_launch_add_block(dwx, lay.Wp, grads->w_ih[0] + lay.E, ld0,
@@ -673,12 +752,12 @@ int pcm_stackgru_backward(const pcm_dims *dims,
         // biases: column sums of the gate gradients
         for (int l = 0; l < L; ++l) {
             const float *G = sv + lay.off_gates[l] + r0 * 4 * H;
-            if (grads->b_ih[l]) {
+            if (grads->b_ih[l] && !bih_done[l]) {
                 r = pcm_colsum_launch(G, 4LL * H, R, 3 * H, grads->b_ih[l],
                                       nullptr, cacc, gs2, gsb, gst);
                 if (r) return r;
             }
-            if (grads->b_hh[l]) {
+            if (grads->b_hh[l] && !bhh_done[l]) {
                 r = pcm_colsum_launch(G, 4LL * H, R, 2 * H, grads->b_hh[l],
                                       nullptr, cacc, gs2, gsb, gst);
                 if (r) return r;
@@ -688,7 +767,7 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                 if (r) return r;
             }
         }
-        if (lay.use_stack) {
+        if (lay.use_stack && !cb_done) {
             const float *dav = sv + lay.off_av + r0 * lay.AVW;
             if (grads->ctrl_b) {
                 r = pcm_colsum_launch(dav, lay.AVW, R, 3, grads->ctrl_b, nullptr,
@@ -834,7 +913,8 @@ int pcm_stackgru_backward(const pcm_dims *dims,
         }
         // the control gradients of step t feed the gate kernel of step t-1
         // only as a READ, so rows >= t are final here
-        if (t > 0 && (T - t) % chunk_steps == 0) {
+        if (t > 0 && next_bound < nbounds && T - t == bounds[next_bound]) {
+            ++next_bound;
             rc = flush_param_grads(t);
             if (rc) return rc;
         }

@@ -40,6 +40,10 @@ struct GemmProb {
     float *C;
     const float *bias;
     const float *alpha_ptr;  // device scalar (nullable -> 1)
+    // optional by-product of the K-major kernel (pcm_gemm_takes_colsum):
+    // colsum1/2[m] (+)= sum_k A[k][m], following `accumulate`
+    float *colsum1, *colsum2;
+    int cs_accumulate;       // -1: as `accumulate`
     long long a_rs, a_cs, b_rs, b_cs, ldc;
     int M, N, K, K1;
     int accumulate;
@@ -57,6 +61,10 @@ size_t pcm_gemm_scratch_bytes(const GemmBatch &batch);
 int pcm_gemm_launch(const GemmBatch &batch, void *scratch,
                     size_t scratch_bytes, hipStream_t stream);
 
+// true if pcm_gemm_launch will run this batch on the K-major kernel, the only
+// one that honours GemmProb::colsum1/2
+bool pcm_gemm_takes_colsum(const GemmBatch &batch, bool have_scratch);
+
 extern int g_pcm_gemm_lds_pad;
 
 static inline GemmProb pcm_gemm_prob(const float *A, long long a_rs,
@@ -66,6 +74,7 @@ static inline GemmProb pcm_gemm_prob(const float *A, long long a_rs,
     GemmProb p;
     p.A = A; p.B = B; p.A2 = nullptr; p.B2 = nullptr; p.C = C;
     p.bias = nullptr; p.alpha_ptr = nullptr;
+    p.colsum1 = nullptr; p.colsum2 = nullptr; p.cs_accumulate = -1;
     p.a_rs = a_rs; p.a_cs = a_cs; p.b_rs = b_rs; p.b_cs = b_cs; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K; p.K1 = 0; p.accumulate = 0;
     return p;

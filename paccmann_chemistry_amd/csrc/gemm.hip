@@ -16,6 +16,7 @@ constexpr int BK = 16;
 
 struct SlabInfo {
     long long off[PCM_GEMM_MAX_PROBS];  // float offset of each problem's slabs
+    long long cs[PCM_GEMM_MAX_PROBS];   // ... of its column-sum partials [splits][M]
 };
 
 // Work-group tile = (64*TM) x (64*TN); 4 waves as 2x2, each TM x TN MFMA tiles.
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmBatch batch,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    float cs0 = 0.f, cs1 = 0.f;  // column sums of A (this lane's k parity)
     if (c0 < c1) {
         // thread -> (k row, 4-wide column group) of the 16 x 128 operand chunks
         const int k_a = tid >> 5, q_a = tid & 31;  // + 8 rows for the second load
@@ -264,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmBatch batch,
             for (int kk = 0; kk < BK; kk += 2) {
                 const float a0 = as[kk * TN_LD], a1 = as[kk * TN_LD + 32];
                 const float b0 = bs[kk * TN_LD], b1 = bs[kk * TN_LD + 32];
+                cs0 += a0; cs1 += a1;
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -292,6 +295,27 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmBatch batch,
         }
     }
 
+    if ((p.colsum1 || p.colsum2) && n0 == 0 && wn == 0) {
+        // the first tile column's left waves hold every A column of the tile
+        cs0 += __shfl_xor(cs0, 32);
+        cs1 += __shfl_xor(cs1, 32);
+        if (lk == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int gm = m0 + wm * 64 + i * 32 + lrow;
+                const float v = i ? cs1 : cs0;
+                if (gm >= p.M) continue;
+                if (splits == 1) {
+                    const int ca =
+                        p.cs_accumulate < 0 ? p.accumulate : p.cs_accumulate;
+                    if (p.colsum1) p.colsum1[gm] = ca ? p.colsum1[gm] + v : v;
+                    if (p.colsum2) p.colsum2[gm] = ca ? p.colsum2[gm] + v : v;
+                } else {
+                    slab[slabs.cs[pz] + (long long)sk * p.M + gm] = v;
+                }
+            }
+        }
+    }
     const float alpha = p.alpha_ptr ? *p.alpha_ptr : 1.0f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -336,6 +360,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmBatch batch,
         float *c = p.C + (long long)m * p.ldc + n;
         if (p.accumulate) v += *c;
         *c = v;
+    }
+    if ((p.colsum1 || p.colsum2) && slabs.cs[blockIdx.y] >= 0) {
+        const float *cb = slab + slabs.cs[blockIdx.y];
+        for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < p.M;
+             m += gridDim.x * blockDim.x) {
+            float s = 0.0f;
+            for (int k = 0; k < splits; ++k) s += cb[(long long)k * p.M + m];
+            const int ca = p.cs_accumulate < 0 ? p.accumulate : p.cs_accumulate;
+            if (p.colsum1) p.colsum1[m] = ca ? p.colsum1[m] + s : s;
+            if (p.colsum2) p.colsum2[m] = ca ? p.colsum2[m] + s : s;
+        }
     }
 }
 
@@ -414,6 +449,11 @@ int tn_splits(const GemmBatch &batch, long long tiles, int minK) {
 
 }  // namespace
 
+bool pcm_gemm_takes_colsum(const GemmBatch &batch, bool have_scratch) {
+    Plan pl = make_plan(batch, have_scratch);
+    return tn_eligible(batch) && (pl.big || tn_long_k(batch));
+}
+
 size_t pcm_gemm_scratch_bytes(const GemmBatch &batch) {
     Plan pl = make_plan(batch, true);
     if (tn_eligible(batch)) pl.splits = std::max(pl.splits, 64);
@@ -459,11 +499,18 @@ int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
     }
     SlabInfo slabs;
     size_t need = 0;
-    for (int i = 0; i < PCM_GEMM_MAX_PROBS; ++i) slabs.off[i] = 0;
+    for (int i = 0; i < PCM_GEMM_MAX_PROBS; ++i) {
+        slabs.off[i] = 0;
+        slabs.cs[i] = -1;
+    }
     if (pl.splits > 1) {
         for (int i = 0; i < batch.count; ++i) {
             slabs.off[i] = (long long)need;
             need += (size_t)pl.splits * batch.p[i].M * batch.p[i].N;
+            if (use_tn && (batch.p[i].colsum1 || batch.p[i].colsum2)) {
+                slabs.cs[i] = (long long)need;
+                need += (size_t)pl.splits * batch.p[i].M;
+            }
         }
         if (need * sizeof(float) > scratch_bytes) {
             pl.splits = 1;  // fall back to a single pass, still correct

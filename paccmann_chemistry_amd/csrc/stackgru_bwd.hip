@@ -11,9 +11,10 @@
 
 namespace {
 
-__device__ __forceinline__ void gate_grad(float d, float *g, int H, int j,
-                                          float hp, float *dh_out) {
-    const float r = g[j], z = g[H + j], n = g[2 * H + j], ghn = g[3 * H + j];
+// gate derivatives from already loaded (r, z, n, ghn, h_{t-1})
+__device__ __forceinline__ void gate_grad_vals(float d, float r, float z, float n,
+                                               float ghn, float hp, float *g,
+                                               int H, int j, float *dh_out) {
     const float dn = d * (1.f - z);
     const float dz = d * (hp - n);
     const float dpn = dn * (1.f - n * n);
@@ -25,6 +26,12 @@ __device__ __forceinline__ void gate_grad(float d, float *g, int H, int j,
     g[2 * H + j] = dpn;       // d(W_in.x + b_in)
     g[3 * H + j] = dpn * r;   // d(W_hn.h + b_hn)
     *dh_out = d * z;
+}
+
+__device__ __forceinline__ void gate_grad(float d, float *g, int H, int j,
+                                          float hp, float *dh_out) {
+    gate_grad_vals(d, g[j], g[H + j], g[2 * H + j], g[3 * H + j], hp, g, H, j,
+                   dh_out);
 }
 
 __global__ __launch_bounds__(256) void gate_bwd_kernel(GateBwdArgs a) {
@@ -219,10 +226,18 @@ constexpr int BCM = 32;         // batch rows per block
 constexpr int BCN = 64;         // output columns per block (2 MFMA tiles)
 constexpr int BA_TILE = BCM * BLDT;
 constexpr int BW_TILE = BCN * BLDT;
-constexpr int BCELL_LDS = 2 * (BA_TILE + BW_TILE);  // floats (52224 B)
+constexpr int BSTAGE = BA_TILE + BW_TILE;   // floats per LDS stage (26112 B)
+constexpr int BNSTAGE = 3;
+constexpr int BCELL_LDS = BNSTAGE * BSTAGE; // 78336 B
 static_assert(BCELL_LDS >= 4 * 2 * 1024, "reduction buffer must fit");
 
-__global__ __launch_bounds__(256) void gru_cell_bwd_kernel(CellBwdArgs a) {
+// Wave-specialised like the forward cell: waves 4-7 stream the operand chunks
+// global -> registers -> LDS (four register sets, unconditional loads, exact
+// vmcnt waits), waves 0-3 read fragments and issue the MFMAs.  The consumer
+// waves issue no global loads inside the loop, so they fetch everything the
+// epilogue needs (running gradients, the lower layer's saved gates: cold HBM
+// lines) at kernel start and only wait for it after the last chunk.
+__global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[BCELL_LDS];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -240,108 +255,160 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(CellBwdArgs a) {
     const int H = a.H, K3 = 3 * H;
     const bool hidden_side = n0 < H;   // tile of dh[l] (uses dnh) or of dx (dni)
     const int nchunks = K3 / BCK;
-
-    // two staging register sets: prefetch distance 2 (see the forward cell)
-    f32x4 ra0[2], rw0[4], ra1[2], rw1[4];
-    const float *ap[2], *wp[4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = tid + 256 * i;
-        const int row = idx >> 4, q = idx & 15;
-        // rows past the batch re-read the last row (never stored)
-        const int b = min(b0 + row, a.B - 1);
-        ap[i] = a.dgates + (long long)b * 4 * H + q * 4;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 256 * i;
-        const int row = idx >> 4, q = idx & 15;  // row 0..63
-        wp[i] = a.wpackT + (long long)(n0 + row) * K3 + q * 4;
-    }
-    auto load_chunk = [&](int c, f32x4 (&ra)[2], f32x4 (&rw)[4]) {
-        const int kb = c * BCK;
-        // dgates columns: [0,2H) shared; third segment dni at 2H, dnh at 3H
-        const int acol = (kb >= 2 * H && hidden_side) ? kb + H : kb;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) ra[i] = *(const f32x4 *)(ap[i] + acol);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rw[i] = *(const f32x4 *)(wp[i] + kb);
-    };
-    auto store_chunk = [&](int buf, const f32x4 (&ra)[2], const f32x4 (&rw)[4]) {
-        float *As = lds + buf * (BA_TILE + BW_TILE);
-        float *Ws = As + BA_TILE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i;
-            *(f32x4 *)(As + (idx >> 4) * BLDT + (idx & 15) * 4) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
-            *(f32x4 *)(Ws + (idx >> 4) * BLDT + (idx & 15) * 4) = rw[i];
-        }
-    };
+    const int last = nchunks - 1;
+    const int npad = (nchunks + 3) & ~3;  // both roles run npad barriers
+    const int lrow = lane & 31, lh = lane >> 5;
 
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    // epilogue operands of this thread's 8 outputs (consumer waves only)
+    float pre_d[8], pre_r[8], pre_z[8], pre_n[8], pre_g[8], pre_h[8];
+    int pre_len[4];
 
-    const int lrow = lane & 31, lh = lane >> 5;
-    auto compute = [&](int buf) {
-        const float *As = lds + buf * (BA_TILE + BW_TILE);
-        const float *Ws = As + BA_TILE;
-        const int koff = wave * 16 + 4 * lh;
-        f32x4 fa[2], f0[2], f1[2];
+    if (wave >= 4) {
+        // ---------------- loader waves ----------------
+        const int lt = tid - 256;
+        const float *ap[2], *wp[4];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            fa[s] = *(const f32x4 *)(As + lrow * BLDT + koff + 8 * s);
-            f0[s] = *(const f32x4 *)(Ws + lrow * BLDT + koff + 8 * s);
-            f1[s] = *(const f32x4 *)(Ws + (32 + lrow) * BLDT + koff + 8 * s);
+        for (int i = 0; i < 2; ++i) {
+            const int idx = lt + 256 * i;
+            const int row = idx >> 4, q = idx & 15;
+            // rows past the batch re-read the last row (never stored)
+            const int b = min(b0 + row, a.B - 1);
+            ap[i] = a.dgates + (long long)b * 4 * H + q * 4;
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int i = 0; i < 4; ++i) {
+            const int idx = lt + 256 * i;
+            const int row = idx >> 4, q = idx & 15;  // row 0..63
+            wp[i] = a.wpackT + (long long)(n0 + row) * K3 + q * 4;
+        }
+        f32x4 ra[4][2], rw[4][4];
+        auto load_chunk = [&](int c, f32x4 (&qa)[2], f32x4 (&qw)[4]) {
+            const int kb = min(c, last) * BCK;
+            // dgates columns: [0,2H) shared; third segment dni at 2H, dnh at 3H
+            const int acol = (kb >= 2 * H && hidden_side) ? kb + H : kb;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][e], f0[s][e],
-                                                            acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][e], f1[s][e],
-                                                            acc1, 0, 0, 0);
+            for (int i = 0; i < 2; ++i) qa[i] = *(const f32x4 *)(ap[i] + acol);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qw[i] = *(const f32x4 *)(wp[i] + kb);
+        };
+        auto store_chunk = [&](int stage, const f32x4 (&qa)[2],
+                               const f32x4 (&qw)[4]) {
+            float *As = lds + stage * BSTAGE;
+            float *Ws = As + BA_TILE;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = lt + 256 * i;
+                *(f32x4 *)(As + (idx >> 4) * BLDT + (idx & 15) * 4) = qa[i];
             }
-    };
-
-    // unconditional loads (tail re-reads the last chunk): straight-line loop
-    // body => exact vmcnt(N) waits, see the forward cell
-    const int last = nchunks - 1;
-    load_chunk(0, ra0, rw0);
-    load_chunk(min(1, last), ra1, rw1);
-    const int npairs = nchunks >> 1;
-    for (int p = 0; p < npairs; ++p) {
-        const int c = 2 * p;
-        store_chunk(0, ra0, rw0);
-        __syncthreads();
-        load_chunk(min(c + 2, last), ra0, rw0);
-        compute(0);
-        store_chunk(1, ra1, rw1);
-        __syncthreads();
-        load_chunk(min(c + 3, last), ra1, rw1);
-        compute(1);
-    }
-    if (nchunks & 1) {
-        store_chunk(0, ra0, rw0);
-        __syncthreads();
-        compute(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = lt + 256 * i;
+                *(f32x4 *)(Ws + (idx >> 4) * BLDT + (idx & 15) * 4) = qw[i];
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_chunk(i, ra[i], rw[i]);
+        store_chunk(0, ra[0], rw[0]);
+        load_chunk(4, ra[0], rw[0]);
+        store_chunk(1, ra[1], rw[1]);
+        load_chunk(5, ra[1], rw[1]);
+        __syncthreads();  // barrier #0: stages 0 and 1 are ready
+        int stage = 2;    // stage of chunk c + 2
+        for (int c = 0; c < npad; c += 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                store_chunk(stage, ra[(i + 2) & 3], rw[(i + 2) & 3]);
+                load_chunk(c + i + 6, ra[(i + 2) & 3], rw[(i + 2) & 3]);
+                stage = stage == BNSTAGE - 1 ? 0 : stage + 1;
+                __syncthreads();
+            }
+        }
+    } else {
+        // ---------------- consumer waves ----------------
+        // epilogue prefetch: element e = tid + 256 q -> tile e >> 10, row
+        // (e & 1023) >> 5, column e & 31 (the mapping of the reduction below)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int b = min(b0 + (tid >> 5) + 8 * q, a.B - 1);
+            pre_len[q] = a.lengths ? a.lengths[b] : 0x7fffffff;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + 256 * q;
+            const int tl = e >> 10, ee = e & 1023;
+            const int b = min(b0 + (ee >> 5), a.B - 1);
+            const int n = n0 + tl * 32 + (ee & 31);
+            pre_d[q] = pre_r[q] = pre_z[q] = pre_n[q] = pre_g[q] = pre_h[q] = 0.f;
+            if (hidden_side) {
+                pre_d[q] = a.dh[(long long)b * a.Hp + n];
+            } else {
+                const int j = min(n - H, a.dx_cols - 1);
+                if (a.gates_low || a.dx_accumulate)
+                    pre_d[q] = a.dx[(long long)b * a.ldx + j];
+                if (a.gates_low) {
+                    const float *g = a.gates_low + (long long)b * 4 * H;
+                    pre_r[q] = g[j]; pre_z[q] = g[H + j];
+                    pre_n[q] = g[2 * H + j]; pre_g[q] = g[3 * H + j];
+                    pre_h[q] = a.hprev_low[(long long)b * a.Hp + j];
+                }
+            }
+        }
+        const int koff = wave * 16 + 4 * lh;
+        f32x4 fa0[2], fb0[2], fc0[2], fa1[2], fb1[2], fc1[2];
+        auto read_frags = [&](int stage, f32x4 (&fa)[2], f32x4 (&f0)[2],
+                              f32x4 (&f1)[2]) {
+            const float *As = lds + stage * BSTAGE;
+            const float *Ws = As + BA_TILE;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                fa[s] = *(const f32x4 *)(As + lrow * BLDT + koff + 8 * s);
+                f0[s] = *(const f32x4 *)(Ws + lrow * BLDT + koff + 8 * s);
+                f1[s] = *(const f32x4 *)(Ws + (32 + lrow) * BLDT + koff + 8 * s);
+            }
+        };
+        auto mfma_chunk = [&](const f32x4 (&fa)[2], const f32x4 (&f0)[2],
+                              const f32x4 (&f1)[2]) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[s][e], f0[s][e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[s][e], f1[s][e], acc1, 0, 0, 0);
+                }
+        };
+        __syncthreads();  // barrier #0
+        read_frags(0, fa0, fb0, fc0);
+        int stage = 1;    // stage of chunk c + 1
+        for (int c = 0; c < npad; c += 2) {
+            read_frags(stage, fa1, fb1, fc1);   // prefetch chunk c + 1
+            if (c < nchunks) mfma_chunk(fa0, fb0, fc0);
+            stage = stage == BNSTAGE - 1 ? 0 : stage + 1;
+            __syncthreads();
+            read_frags(stage, fa0, fb0, fc0);   // prefetch chunk c + 2
+            if (c + 1 < nchunks) mfma_chunk(fa1, fb1, fc1);
+            stage = stage == BNSTAGE - 1 ? 0 : stage + 1;
+            __syncthreads();
+        }
     }
 
     __syncthreads();
     float *red = lds;  // [wave][tile][32][32]
+    if (wave < 4) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        float *base = red + (wave * 2) * 1024 + row * 32 + lrow;
-        base[0] = acc0[r];
-        base[1024] = acc1[r];
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float *base = red + (wave * 2) * 1024 + row * 32 + lrow;
+            base[0] = acc0[r];
+            base[1024] = acc1[r];
+        }
     }
     __syncthreads();
+    if (wave >= 4) return;
 
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -354,7 +421,7 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(CellBwdArgs a) {
         const int b = b0 + row, n = n0 + tl * 32 + col;
         if (b >= a.B) continue;
         if (hidden_side) {
-            a.dh[(long long)b * a.Hp + n] += v;
+            a.dh[(long long)b * a.Hp + n] = pre_d[q] + v;
         } else {
             const int j = n - H;
             if (j >= a.dx_cols) continue;
@@ -365,18 +432,18 @@ __global__ __launch_bounds__(256) void gru_cell_bwd_kernel(CellBwdArgs a) {
             if (a.gates_low) {
                 // v completes dL/dh_t of the layer below: take its gate
                 // derivatives right here (saves a launch per step)
-                const float d = *dst + v;
+                const float d = pre_d[q] + v;
                 float *g = a.gates_low + (long long)b * 4 * H;
-                if (a.lengths && a.t >= a.lengths[b]) {
+                if (a.t >= pre_len[q & 3]) {
                     g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f;
                     g[3 * H + j] = 0.f;
                     *dst = d;
                 } else {
-                    gate_grad(d, g, H, j,
-                              a.hprev_low[(long long)b * a.Hp + j], dst);
+                    gate_grad_vals(d, pre_r[q], pre_z[q], pre_n[q], pre_g[q],
+                                   pre_h[q], g, H, j, dst);
                 }
             } else {
-                *dst = a.dx_accumulate ? *dst + v : v;
+                *dst = a.dx_accumulate ? pre_d[q] + v : v;
             }
         }
     }
@@ -445,7 +512,7 @@ int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream) {
     b.reg_cols = (nct + 3) / 4;
     b.reg_rows = (nbt + 1) / 2;
     dim3 grid(8 * b.reg_cols * b.reg_rows);
-    hipLaunchKernelGGL(gru_cell_bwd_kernel, grid, dim3(256), 0, stream, b);
+    hipLaunchKernelGGL(gru_cell_bwd_kernel, grid, dim3(512), 0, stream, b);
     return 0;
 }
 
