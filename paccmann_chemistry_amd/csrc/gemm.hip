@@ -191,7 +191,10 @@ struct TileMap {
     int tiles_n[PCM_GEMM_MAX_PROBS];
 };
 
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmBatch batch,
+// FIXED_MODE 0: every problem of the batch is wide (the wave mapping folds at
+// compile time: fewer registers, 3 waves per SIMD); -1: chosen per problem.
+template <int FIXED_MODE>
+__global__ __launch_bounds__(256, FIXED_MODE == 0 ? 3 : 2) void gemm_tn_kernel(GemmBatch batch,
                                                          int splits, float *slab,
                                                          SlabInfo slabs,
                                                          TileMap tm) {
@@ -220,8 +223,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmBatch batch,
     const int c0 = sk * cps;
     const int c1 = min(nchunks, c0 + cps);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane & 31, lk = lane >> 5;
+    // wave -> 32 x 32 sub-tiles.  mode 0: 2 x 2 quadrant of the 128 x 128 tile;
+    // narrow problems keep all four SIMDs on valid data: mode 1 (N <= 64) gives
+    // each wave one 32-row strip x 2 column tiles, mode 2 (M <= 64) one 32-column
+    // strip x 2 row tiles (acc[i][j] is then indexed [0][j] / [i][0]).
+    const int mode =
+        FIXED_MODE >= 0 ? FIXED_MODE : (p.N <= 64 ? 1 : (p.M <= 64 ? 2 : 0));
+    const int wm = mode == 0 ? wave >> 1 : 0, wn = mode == 0 ? wave & 1 : 0;
+    const int rbase = mode == 0 ? wm * 64 : (mode == 1 ? wave * 32 : 0);
+    const int cbase = mode == 0 ? wn * 64 : (mode == 2 ? wave * 32 : 0);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -260,17 +271,37 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmBatch batch,
             *(f32x4 *)(&Bs[buf][lofs + 8 * TN_LD]) = qb[1];
         };
         auto compute = [&](int buf) {
-            const float *as = &As[buf][lk * TN_LD + wm * 64 + lrow];
-            const float *bs = &Bs[buf][lk * TN_LD + wn * 64 + lrow];
+            const float *as = &As[buf][lk * TN_LD + rbase + lrow];
+            const float *bs = &Bs[buf][lk * TN_LD + cbase + lrow];
+            if (mode == 0) {
 #pragma unroll
-            for (int kk = 0; kk < BK; kk += 2) {
-                const float a0 = as[kk * TN_LD], a1 = as[kk * TN_LD + 32];
-                const float b0 = bs[kk * TN_LD], b1 = bs[kk * TN_LD + 32];
-                cs0 += a0; cs1 += a1;
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                for (int kk = 0; kk < BK; kk += 2) {
+                    const float a0 = as[kk * TN_LD], a1 = as[kk * TN_LD + 32];
+                    const float b0 = bs[kk * TN_LD], b1 = bs[kk * TN_LD + 32];
+                    cs0 += a0; cs1 += a1;
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                }
+            } else if (mode == 1) {
+#pragma unroll
+                for (int kk = 0; kk < BK; kk += 2) {
+                    const float a0 = as[kk * TN_LD];
+                    const float b0 = bs[kk * TN_LD], b1 = bs[kk * TN_LD + 32];
+                    cs0 += a0;
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < BK; kk += 2) {
+                    const float a0 = as[kk * TN_LD], a1 = as[kk * TN_LD + 32];
+                    const float b0 = bs[kk * TN_LD];
+                    cs0 += a0; cs1 += a1;
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                }
             }
         };
         load_chunk(c0, ra[0], rb[0]);
@@ -295,14 +326,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmBatch batch,
         }
     }
 
-    if ((p.colsum1 || p.colsum2) && n0 == 0 && wn == 0) {
+    if ((p.colsum1 || p.colsum2) && n0 == 0 &&
+        (mode == 0 ? wn == 0 : (mode == 1 || wave == 0))) {
         // the first tile column's left waves hold every A column of the tile
         cs0 += __shfl_xor(cs0, 32);
         cs1 += __shfl_xor(cs1, 32);
         if (lk == 0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int gm = m0 + wm * 64 + i * 32 + lrow;
+                if (mode == 1 && i == 1) continue;
+                const int gm = m0 + rbase + i * 32 + lrow;
                 const float v = i ? cs1 : cs0;
                 if (gm >= p.M) continue;
                 if (splits == 1) {
@@ -321,12 +354,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(GemmBatch batch,
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int gn = n0 + (wn * 2 + j) * 32 + lrow;
+            if ((mode == 1 && i == 1) || (mode == 2 && j == 1)) continue;
+            const int gn = n0 + cbase + j * 32 + lrow;
             if (gn >= p.N) continue;
             const float bias = (p.bias && splits == 1) ? p.bias[gn] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) +
+                const int gm = m0 + rbase + i * 32 + (r & 3) + 8 * (r >> 2) +
                                4 * lk;
                 if (gm >= p.M) continue;
                 if (splits == 1) {
@@ -519,9 +553,18 @@ int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
     dim3 grid(pl.gx, pl.gy, batch.count * pl.splits);
     float *slab = (float *)scratch;
     if (use_tn) {
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(tn_tiles * pl.splits)),
-                           dim3(256), g_pcm_gemm_lds_pad, stream, batch,
-                           pl.splits, slab, slabs, tmap);
+        bool wide = true;
+        for (int i = 0; i < batch.count; ++i)
+            wide = wide && batch.p[i].M > 64 && batch.p[i].N > 64;
+        const dim3 tn_grid((unsigned)(tn_tiles * pl.splits));
+        if (wide)
+            hipLaunchKernelGGL(gemm_tn_kernel<0>, tn_grid, dim3(256),
+                               g_pcm_gemm_lds_pad, stream, batch, pl.splits,
+                               slab, slabs, tmap);
+        else
+            hipLaunchKernelGGL(gemm_tn_kernel<-1>, tn_grid, dim3(256),
+                               g_pcm_gemm_lds_pad, stream, batch, pl.splits,
+                               slab, slabs, tmap);
     } else if (pl.big)
         hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), g_pcm_gemm_lds_pad,
                            stream,

@@ -43,6 +43,17 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(GateBwdArgs a) {
     const int NO = 3 + a.W;
     float *dh = a.dh + (long long)b * a.Hp + j;
     float d = *dh;
+    // the saved gates, h_{t-1} and the output gradient are cold HBM lines:
+    // issue their loads first so the control mat-vec below hides the latency
+    float *g = a.gates + (long long)b * 4 * a.H;
+    float gr = 0.f, gz = 0.f, gn = 0.f, gh = 0.f, hp = 0.f, dout = 0.f;
+    bool frozen = false;
+    if (!a.ctrl_only) {
+        gr = g[j]; gz = g[a.H + j]; gn = g[2 * a.H + j]; gh = g[3 * a.H + j];
+        hp = a.hprev[(long long)b * a.Hp + j];
+        if (a.dout) dout = a.dout[(long long)b * a.ld_dout + j];
+        frozen = a.lengths && a.t >= a.lengths[b];
+    }
     if (a.dcu) {
         // stack-control path of step t+1 (zero for rows frozen there)
         const float *dc = a.dcu + (long long)b * a.AVW;
@@ -56,16 +67,14 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(GateBwdArgs a) {
         d += s;
     }
     if (a.ctrl_only) { *dh = d; return; }
-    float *g = a.gates + (long long)b * 4 * a.H;
-    if (a.lengths && a.t >= a.lengths[b]) {
+    if (frozen) {
         // frozen row: h_t = h_{t-1}; its output carries no gradient
         g[j] = 0.f; g[a.H + j] = 0.f; g[2 * a.H + j] = 0.f;
         g[3 * a.H + j] = 0.f;
         *dh = d;
         return;
     }
-    if (a.dout) d += a.dout[(long long)b * a.ld_dout + j];
-    gate_grad(d, g, a.H, j, a.hprev[(long long)b * a.Hp + j], dh);
+    gate_grad_vals(d + dout, gr, gz, gn, gh, hp, g, a.H, j, dh);
 }
 
 // One block of 512 threads per BROWS batch rows.  S_{t-1} and dL/dS'_t of the
