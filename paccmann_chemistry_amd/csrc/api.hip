@@ -186,7 +186,7 @@ int pcm_sg_layout(const pcm_dims *d, int steps, int training, int dropout,
     return PCM_OK;
 }
 
-static const size_t GEMM_SCRATCH_FLOATS = 26u * 1024u * 1024u;
+static const size_t GEMM_SCRATCH_FLOATS = 40u * 1024u * 1024u;
 
 int pcm_sg_scratch(const SGLayout &lay, SGScratch *o) {
     memset(o, 0, sizeof(*o));

@@ -467,18 +467,33 @@ bool tn_long_k(const GemmBatch &batch) {
     return true;
 }
 
-int tn_splits(const GemmBatch &batch, long long tiles, int minK) {
+// Split count of a K-major launch: a multiple of 8 (XCD-private K ranges) that
+// fills whole rounds of co-resident blocks (3 per CU for wide batches, 2 for
+// narrow ones), keeps >= 256 rows per split and fits the slab scratch.
+int tn_splits(const GemmBatch &batch, long long tiles, int minK, bool wide,
+              size_t scratch_bytes) {
     static const int forced = [] {
         const char *e = getenv("PCM_TN_SPLITS");
         return e ? atoi(e) : 0;
     }();
     const int chunks = minK / BK;
-    int splits = forced > 0 ? forced : 8;
-    if (forced <= 0)
-        while (tiles * splits < 1024 && splits < 64) splits += 8;
-    while (splits > 8 && chunks / splits < 16) splits -= 8;
-    if (chunks / splits < 16) splits = std::max(1, std::min(splits, chunks / 16));
-    return splits;
+    size_t per_split = 0;
+    for (int i = 0; i < batch.count; ++i)
+        per_split += (size_t)batch.p[i].M * (batch.p[i].N + 1);
+    const long long conc = 256LL * (wide ? 3 : 2);
+    int best = 0;
+    double best_eff = -1.0;
+    for (int sp = 8; sp <= 64; sp += 8) {
+        if (chunks / sp < 16) break;
+        if (per_split * sp * sizeof(float) > scratch_bytes) break;
+        const long long blocks = tiles * sp;
+        const long long rounds = (blocks + conc - 1) / conc;
+        const double eff = (double)blocks / (double)(rounds * conc);
+        if (eff > best_eff + 0.02) { best_eff = eff; best = sp; }
+    }
+    if (forced > 0) best = forced;
+    if (best == 0) best = std::max(1, std::min(8, chunks / 16));
+    return best;
 }
 
 }  // namespace
@@ -529,7 +544,12 @@ int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
         tmap.first[PCM_GEMM_MAX_PROBS] = (int)tn_tiles;
         for (int i = batch.count; i <= PCM_GEMM_MAX_PROBS; ++i)
             tmap.first[i] = (int)tn_tiles;
-        pl.splits = scratch ? tn_splits(batch, tn_tiles, minK) : 1;
+        bool wide_batch = true;
+        for (int i = 0; i < batch.count; ++i)
+            wide_batch = wide_batch && batch.p[i].M > 64 && batch.p[i].N > 64;
+        pl.splits = scratch ? tn_splits(batch, tn_tiles, minK, wide_batch,
+                                        scratch_bytes)
+                            : 1;
     }
     SlabInfo slabs;
     size_t need = 0;
