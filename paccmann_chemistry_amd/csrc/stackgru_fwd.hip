@@ -284,9 +284,29 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
         }
     }
 
-    // stage previous stacks (vectorised when the row size allows it)
-    if ((DW & 3) == 0) {
-        const int nq = DW >> 2;
+    // top-layer hidden rows -> LDS (needed first, by the dot products)
+    for (int idx = tid; idx < SROWS * H; idx += STHREADS) {
+        const int r = pcm_fdiv(idx, inv_H), k = idx - r * H;
+        const int b = b0 + r;
+        hrow[idx] = b < a.B ? a.htop[(long long)b * a.Hp + k] : 0.f;
+    }
+    // previous stacks: the loads are issued now, into registers, and only
+    // parked in LDS after the dot products, which hide their latency
+    // (vectorised when the row size allows it)
+    constexpr int SQ = 4;  // float4 per thread held in flight
+    const bool vec = (DW & 3) == 0;
+    const int nq = DW >> 2;
+    const bool sregs = vec && SROWS * nq <= SQ * STHREADS;
+    f32x4 sq[SQ];
+    if (sregs) {
+#pragma unroll
+        for (int i = 0; i < SQ; ++i) {
+            const int idx = min(tid + STHREADS * i, SROWS * nq - 1);
+            const int r = pcm_fdiv(idx, inv_nq), q = idx - r * nq;
+            const int b = min(b0 + r, a.B - 1);
+            sq[i] = *(const f32x4 *)(a.S_prev + (long long)b * DW + q * 4);
+        }
+    } else if (vec) {
         for (int idx = tid; idx < SROWS * nq; idx += STHREADS) {
             const int r = pcm_fdiv(idx, inv_nq), q = idx - r * nq;
             const int b = b0 + r;
@@ -301,11 +321,6 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
             const int b = b0 + r;
             Srow[r * DWp + e] = b < a.B ? a.S_prev[(long long)b * DW + e] : 0.f;
         }
-    }
-    for (int idx = tid; idx < SROWS * H; idx += STHREADS) {
-        const int r = pcm_fdiv(idx, inv_H), k = idx - r * H;
-        const int b = b0 + r;
-        hrow[idx] = b < a.B ? a.htop[(long long)b * a.Hp + k] : 0.f;
     }
     __syncthreads();
 
@@ -396,6 +411,16 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
             }
         }
     }
+    if (sregs) {
+#pragma unroll
+        for (int i = 0; i < SQ; ++i) {
+            const int idx = tid + STHREADS * i;
+            if (idx < SROWS * nq) {
+                const int r = pcm_fdiv(idx, inv_nq), q = idx - r * nq;
+                *(f32x4 *)(Srow + r * DWp + q * 4) = sq[i];
+            }
+        }
+    }
     __syncthreads();
 
     // softmax over the 3 controls (one thread per row), tanh of the push value
@@ -418,24 +443,48 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
         const int b = b0 + r;
         if (b < a.B) a.av[(long long)b * a.AVW + o] = o < NO ? cu[idx] : 0.f;
     }
-    for (int idx = tid; idx < SROWS * DW; idx += STHREADS) {
-        const int r = pcm_fdiv(idx, inv_DW), e = idx - r * DW;
-        const int b = b0 + r;
-        if (b >= a.B) continue;
+    auto updated = [&](int r, int e, bool frozen, float *top_w) -> float {
         const int d = pcm_fdiv(e, inv_W), w = e - d * W;
         const float *Sp = Srow + r * DWp;
-        const float s = Sp[e];
-        float nv = s;
-        if (!(a.lengths && a.t >= a.lengths[b])) {
+        const float sv = Sp[e];
+        float nv = sv;
+        if (!frozen) {
             const float *c = cu + r * a.AVW;
             const float up = d == 0 ? c[3 + w] : Sp[e - W];
             const float dn = d == D - 1 ? 0.f : Sp[e + W];
             // reference order: no_op*S, + push*up, + pop*down (stack_rnn.py:229-231)
-            nv = __fadd_rn(__fadd_rn(__fmul_rn(c[2], s), __fmul_rn(c[0], up)),
+            nv = __fadd_rn(__fadd_rn(__fmul_rn(c[2], sv), __fmul_rn(c[0], up)),
                            __fmul_rn(c[1], dn));
         }
-        a.S_new[(long long)b * DW + e] = nv;
-        if (d == 0) a.xtop[(long long)b * a.Wp + w] = nv;
+        if (d == 0) *top_w = nv;
+        return nv;
+    };
+    if (vec) {
+        for (int idx = tid; idx < SROWS * nq; idx += STHREADS) {
+            const int r = pcm_fdiv(idx, inv_nq), q = idx - r * nq;
+            const int b = b0 + r;
+            if (b >= a.B) continue;
+            const bool frozen = a.lengths && a.t >= a.lengths[b];
+            float *xt = a.xtop + (long long)b * a.Wp;
+            f32x4 nv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = q * 4 + i;
+                float dummy;
+                nv[i] = updated(r, e, frozen, e < W ? xt + e : &dummy);
+            }
+            *(f32x4 *)(a.S_new + (long long)b * DW + q * 4) = nv;
+        }
+    } else {
+        for (int idx = tid; idx < SROWS * DW; idx += STHREADS) {
+            const int r = pcm_fdiv(idx, inv_DW), e = idx - r * DW;
+            const int b = b0 + r;
+            if (b >= a.B) continue;
+            const bool frozen = a.lengths && a.t >= a.lengths[b];
+            float dummy;
+            a.S_new[(long long)b * DW + e] = updated(
+                r, e, frozen, e < W ? a.xtop + (long long)b * a.Wp + e : &dummy);
+        }
     }
     const int padw = a.Wp - W;
     const float inv_padw = 1.0f / (float)max(padw, 1);
