@@ -7,6 +7,8 @@
 //   gru_cell_fwd    one GRU layer: [x | h] . Wpack^T on fp32 MFMA (32x32x2),
 //                   LDS-staged 64-wide K chunks, intra-block split-K over the
 //                   4 waves, gate math + token-gate gather in the epilogue
+#include <stdlib.h>
+
 #include "stackgru.h"
 
 namespace {
@@ -51,22 +53,27 @@ __global__ __launch_bounds__(512) void gru_cell_fwd_kernel(CellFwdArgs a) {
     if (wave >= 4) {
         // ---------------- loader waves ----------------
         const int lt = tid - 256;
-        const float *ax[2], *ah[2], *wp[6];
+        // uniform base pointer (SGPRs, advanced per chunk on the scalar unit)
+        // + a fixed 32-bit byte offset per thread: the loads need no vector
+        // address arithmetic inside the loop
+        const char *xb = (const char *)a.xin, *hb = (const char *)a.hprev;
+        const char *wb = (const char *)a.wpack;
+        uint32_t offx[2], offh[2], offw[6];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = lt + 256 * i;
             const int row = idx >> 4, q = idx & 15;
             // rows past the batch re-read the last row (never stored)
             const int b = min(b0 + row, a.B - 1);
-            ax[i] = a.xin + (long long)b * a.ldx + q * 4;
-            ah[i] = a.hprev + (long long)b * a.Hp + q * 4;
+            offx[i] = (uint32_t)(b * a.ldx + q * 4) * 4u;
+            offh[i] = (uint32_t)(b * a.Hp + q * 4) * 4u;
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int idx = lt + 256 * i;
             const int row = idx >> 4, q = idx & 15;  // row 0..95
             const int g = row >> 5, jj = row & 31;
-            wp[i] = a.wpack + (long long)(g * a.Hn + j0 + jj) * a.Kp + q * 4;
+            offw[i] = (uint32_t)((g * a.Hn + j0 + jj) * a.Kp + q * 4) * 4u;
         }
         // FOUR staging register sets: a chunk's loads are issued 4-6 chunks
         // before its data is needed (128 KB in flight per CU), which is what
@@ -77,13 +84,15 @@ __global__ __launch_bounds__(512) void gru_cell_fwd_kernel(CellFwdArgs a) {
         auto load_chunk = [&](int c, f32x4 (&qa)[2], f32x4 (&qw)[6]) {
             c = min(c, last);
             const bool xpart = c < a.nx_chunks;
-            const int kb = (xpart ? c : c - a.nx_chunks) * CK;
+            const int kb = (xpart ? c : c - a.nx_chunks) * (CK * 4);
+            const char *ab = (xpart ? xb : hb) + kb;
+            const char *wc = wb + c * (CK * 4);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                qa[i] = *(const f32x4 *)((xpart ? ax[i] : ah[i]) + kb);
+                qa[i] = *(const f32x4 *)(ab + (xpart ? offx[i] : offh[i]));
 #pragma unroll
             for (int i = 0; i < 6; ++i)
-                qw[i] = *(const f32x4 *)(wp[i] + c * CK);
+                qw[i] = *(const f32x4 *)(wc + offw[i]);
         };
         auto store_chunk = [&](int stage, const f32x4 (&qa)[2],
                                const f32x4 (&qw)[6]) {
@@ -176,6 +185,261 @@ __global__ __launch_bounds__(512) void gru_cell_fwd_kernel(CellFwdArgs a) {
             if (c + 1 < nchunks) mfma_chunk(c + 1, fa1, fr1, fz1, fn1);
             stage = stage == NSTAGE - 1 ? 0 : stage + 1;
             __syncthreads();
+        }
+    }
+
+    // cross-wave reduction of the 4 partial tiles through LDS
+    __syncthreads();
+    float *red = lds;  // [wave][tile][32][32]
+    if (wave < 4) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float *base = red + (wave * 4) * 1024 + row * 32 + lrow;
+            base[0 * 1024] = acc_r[r];
+            base[1 * 1024] = acc_z[r];
+            base[2 * 1024] = acc_ni[r];
+            base[3 * 1024] = acc_nh[r];
+        }
+    }
+    __syncthreads();
+
+    const int H = a.H, Hn = a.Hn;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = tid + 512 * q;
+        const int row = e >> 5, col = e & 31;
+        const int b = b0 + row, j = j0 + col;
+        float s[4];
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += red[(w * 4 + tl) * 1024 + e];
+            s[tl] = v;
+        }
+        if (b >= a.B || j >= H) continue;
+        float tr = 0.f, tz = 0.f, tn = 0.f;
+        if (a.tokg) {
+            long long tk = a.tok[b];
+            if (tk < 0 || tk >= a.V) {
+                tk = tk < 0 ? 0 : a.V - 1;
+                if (a.status) atomicOr(a.status, PCM_STATUS_BAD_TOKEN);
+            }
+            const float *tg = a.tokg + tk * (3LL * Hn);
+            tr = tg[j]; tz = tg[Hn + j]; tn = tg[2 * Hn + j];
+        }
+        const float r_ = pcm_sigmoid(s[0] + a.bpack[j] + tr);
+        const float z_ = pcm_sigmoid(s[1] + a.bpack[Hn + j] + tz);
+        const float ghn = s[3] + a.bpack[3 * Hn + j];
+        const float n_ = tanhf(s[2] + a.bpack[2 * Hn + j] + tn + r_ * ghn);
+        const float hp = a.hprev[(long long)b * a.Hp + j];
+        // ATen GRU cell: (h - n) * z + n
+        float hn = __fadd_rn(__fmul_rn(hp - n_, z_), n_);
+        if (a.lengths && a.t >= a.lengths[b]) hn = hp;
+        a.hnew[(long long)b * a.Hp + j] = hn;
+        if (a.gates) {
+            float *g = a.gates + (long long)b * 4 * H;
+            g[j] = r_; g[H + j] = z_; g[2 * H + j] = n_; g[3 * H + j] = ghn;
+        }
+        if (a.xdrop)
+            a.xdrop[(long long)b * a.Hp + j] =
+                hn * pcm_dropout_scale(a.seed, a.next_layer, a.t, b, j,
+                                       a.drop_p, a.inv_keep);
+    }
+}
+
+// ------------------------------------------------------------------------------
+// The same cell with LDS-DMA staging (global_load_lds_dwordx4): the loader waves
+// issue loads that land in LDS directly -- no staging registers, no ds_write
+// pass, no vector address arithmetic.  An LDS-DMA wave instruction writes 1 KiB
+// lane-linear, so rows are unpadded (256 B) and bank conflicts are avoided by an
+// XOR swizzle of the 16-byte granule index with (row & 15), applied on the
+// SOURCE address by the loaders and on the LDS address by the consumers.
+// Four 32 KiB stages; the loaders keep two chunks in flight across each raw
+// s_barrier (counted vmcnt, never __syncthreads inside the loop, which would
+// drain the DMA queue).
+// ------------------------------------------------------------------------------
+constexpr int GSTAGE = (CM + 3 * CN) * CK;   // floats per stage (32 KiB)
+constexpr int GNSTAGE = 4;
+constexpr int GCELL_LDS = GNSTAGE * GSTAGE;  // 128 KiB
+static_assert(GCELL_LDS >= 4 * 4 * 1024, "reduction buffer must fit");
+
+// Eight LDS-DMA loads of one loader wave: lane offsets off[i] (bytes) from the
+// uniform base, destinations lds_byte + 1 KiB * i.  Inline asm on purpose: hipcc
+// drains the DMA queue (vmcnt(0)) between builtin calls whose LDS destinations
+// it cannot tell apart; the waits are counted by hand in the caller.  M0 (the
+// DMA's LDS base) is saved and restored inside the statement.
+__device__ __forceinline__ void glds8(const char *base, const uint32_t (&off)[8],
+                                      uint32_t lds_byte) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %5, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %6, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %7, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %8, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %9, %1\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %10, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(base), "s"(lds_byte), "v"(off[0]), "v"(off[1]), "v"(off[2]),
+          "v"(off[3]), "v"(off[4]), "v"(off[5]), "v"(off[6]), "v"(off[7])
+        : "memory", "scc");
+}
+
+__device__ __forceinline__ void raw_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+__global__ __launch_bounds__(512) void gru_cell_fwd_glds_kernel(CellFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[GCELL_LDS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    // wave index as a scalar: role branches and LDS-DMA bases stay on the SALU
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j0 = blockIdx.x * CN;   // first hidden unit of the tile
+    const int b0 = blockIdx.y * CM;   // first batch row
+    const int nchunks = a.nx_chunks + a.nh_chunks;
+    const int last = nchunks - 1;
+    const int npad = (nchunks + 3) & ~3;  // both roles run npad barriers
+    const int lrow = lane & 31, lh = lane >> 5;
+
+    f32x16 acc_r, acc_z, acc_ni, acc_nh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc_r[r] = 0.f; acc_z[r] = 0.f; acc_ni[r] = 0.f; acc_nh[r] = 0.f;
+    }
+
+    if (wave >= 4) {
+        // ---------------- loader waves ----------------
+        // wave lw issues instructions 8*lw .. 8*lw+7 of a chunk; instruction q
+        // fills stage rows 4q .. 4q+3 (rows 0-31: activations, 32-127: weights);
+        // lane -> (row 4q + lane/16, granule slot lane%16)
+        const int lw = wave - 4;
+        const char *xb = (const char *)a.xin, *hb = (const char *)a.hprev;
+        const char *wb = (const char *)a.wpack;
+        uint32_t off0[8], off1[8];  // lw == 0: x / h offsets; else weights in off0
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * (lw * 8 + i) + (lane >> 4);
+            const int g = (lane & 15) ^ (row & 15);   // source granule (swizzle)
+            if (lw == 0) {
+                // rows past the batch re-read the last row (never stored)
+                const int b = min(b0 + row, a.B - 1);
+                off0[i] = (uint32_t)(b * a.ldx + g * 4) * 4u;
+                off1[i] = (uint32_t)(b * a.Hp + g * 4) * 4u;
+            } else {
+                const int wr = row - CM, gate = wr >> 5, jj = wr & 31;
+                off0[i] = (uint32_t)((gate * a.Hn + j0 + jj) * a.Kp + g * 4) * 4u;
+                off1[i] = 0;
+            }
+        }
+        const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(size_t)(__attribute__((address_space(3))) void *)lds);
+        auto issue = [&](int cc) {
+            const int c = min(cc, last);   // the tail re-reads the last chunk
+            const uint32_t dst =
+                lds0 + ((cc & (GNSTAGE - 1)) * GSTAGE + lw * 8 * 256) * 4u;
+            if (lw == 0) {
+                if (c < a.nx_chunks)
+                    glds8(xb + c * (CK * 4), off0, dst);
+                else
+                    glds8(hb + (c - a.nx_chunks) * (CK * 4), off1, dst);
+            } else {
+                glds8(wb + c * (CK * 4), off0, dst);
+            }
+        };
+        issue(0); issue(1); issue(2); issue(3);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // chunks 0, 1 landed
+        raw_barrier();                                      // barrier #0
+        raw_barrier();  // #0b: the consumers hold chunk 0's fragments
+        for (int k = 0; k < npad; ++k) {
+            // stage of chunk k is free: its fragments were read before the
+            // barrier that ended iteration k - 1
+            issue(k + 4);
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // chunk k+2 landed
+            raw_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // ---------------- consumer waves ----------------
+        // this wave's 16-wide k slice; lane half lh supplies k = 8s + 4*lh + e,
+        // i.e. granule 4*wave + lh + 2s of its row, stored at slot ^ (row & 15)
+        int slot[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            slot[s] = lrow * CK + (((4 * wave + lh + 2 * s) ^ (lrow & 15)) << 2);
+        f32x4 fa0[2], fr0[2], fz0[2], fn0[2];
+        f32x4 fa1[2], fr1[2], fz1[2], fn1[2];
+        auto read_frags = [&](int cc, f32x4 (&fa)[2], f32x4 (&fr)[2],
+                              f32x4 (&fz)[2], f32x4 (&fn)[2]) {
+            const float *As = lds + (cc & (GNSTAGE - 1)) * GSTAGE;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                fa[s] = *(const f32x4 *)(As + slot[s]);
+                fr[s] = *(const f32x4 *)(As + (CM + 0 * CN) * CK + slot[s]);
+                fz[s] = *(const f32x4 *)(As + (CM + 1 * CN) * CK + slot[s]);
+                fn[s] = *(const f32x4 *)(As + (CM + 2 * CN) * CK + slot[s]);
+            }
+        };
+        auto mfma_chunk = [&](int c, const f32x4 (&fa)[2], const f32x4 (&fr)[2],
+                              const f32x4 (&fz)[2], const f32x4 (&fn)[2]) {
+            if (c < a.nx_chunks) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            fa[s][e], fr[s][e], acc_r, 0, 0, 0);
+                        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            fa[s][e], fz[s][e], acc_z, 0, 0, 0);
+                        acc_ni = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            fa[s][e], fn[s][e], acc_ni, 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            fa[s][e], fr[s][e], acc_r, 0, 0, 0);
+                        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            fa[s][e], fz[s][e], acc_z, 0, 0, 0);
+                        acc_nh = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            fa[s][e], fn[s][e], acc_nh, 0, 0, 0);
+                    }
+            }
+        };
+        raw_barrier();  // barrier #0
+        read_frags(0, fa0, fr0, fz0, fn0);
+        raw_barrier();  // #0b: stage 0 may be refilled from here on
+        for (int c = 0; c < npad; c += 2) {
+            read_frags(c + 1, fa1, fr1, fz1, fn1);   // prefetch chunk c + 1
+            if (c < nchunks) mfma_chunk(c, fa0, fr0, fz0, fn0);
+            raw_barrier();
+            read_frags(c + 2, fa0, fr0, fz0, fn0);   // prefetch chunk c + 2
+            if (c + 1 < nchunks) mfma_chunk(c + 1, fa1, fr1, fz1, fn1);
+            raw_barrier();
         }
     }
 
@@ -587,7 +851,12 @@ int grid_for(long long n) {
 
 int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
     dim3 grid(a.Hn / CN, (a.B + CM - 1) / CM);
-    hipLaunchKernelGGL(gru_cell_fwd_kernel, grid, dim3(512), 0, stream, a);
+    static const bool glds = getenv("PCM_CELL_GLDS") != nullptr;
+    if (glds)
+        hipLaunchKernelGGL(gru_cell_fwd_glds_kernel, grid, dim3(512), 0, stream,
+                           a);
+    else
+        hipLaunchKernelGGL(gru_cell_fwd_kernel, grid, dim3(512), 0, stream, a);
     return 0;
 }
 
