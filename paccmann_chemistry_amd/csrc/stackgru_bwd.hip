@@ -230,26 +230,64 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
 // intra-block split-K over the 4 waves, accumulate / dropout-mask epilogue
 // ------------------------------------------------------------------------------
 constexpr int BCK = 64;         // K per chunk
-constexpr int BLDT = BCK + 4;   // LDS row stride (floats)
 constexpr int BCM = 32;         // batch rows per block
 constexpr int BCN = 64;         // output columns per block (2 MFMA tiles)
-constexpr int BA_TILE = BCM * BLDT;
-constexpr int BW_TILE = BCN * BLDT;
-constexpr int BSTAGE = BA_TILE + BW_TILE;   // floats per LDS stage (26112 B)
-constexpr int BNSTAGE = 3;
-constexpr int BCELL_LDS = BNSTAGE * BSTAGE; // 78336 B
+constexpr int BSTAGE = (BCM + BCN) * BCK;   // floats per LDS stage (24 KiB)
+constexpr int BNSTAGE = 4;
+constexpr int BCELL_LDS = BNSTAGE * BSTAGE; // 96 KiB
 static_assert(BCELL_LDS >= 4 * 2 * 1024, "reduction buffer must fit");
 
 // Wave-specialised like the forward cell: waves 4-7 stream the operand chunks
-// global -> registers -> LDS (four register sets, unconditional loads, exact
-// vmcnt waits), waves 0-3 read fragments and issue the MFMAs.  The consumer
-// waves issue no global loads inside the loop, so they fetch everything the
-// epilogue needs (running gradients, the lower layer's saved gates: cold HBM
-// lines) at kernel start and only wait for it after the last chunk.
+// into LDS with LDS-DMA loads (global_load_lds_dwordx4; unpadded 256-byte rows,
+// 16-byte granules XOR-swizzled with (row & 15) on the source address; four
+// stages, one chunk in flight across each raw barrier, hand-counted vmcnt),
+// waves 0-3 read fragments and issue the MFMAs.  The consumer waves issue no
+// global loads inside the loop, so they fetch everything the epilogue needs
+// (running gradients, the lower layer's saved gates: cold HBM lines) at kernel
+// start and only wait for it after the last chunk.
+__device__ __forceinline__ void glds6(const char *const (&base)[6],
+                                      const uint32_t (&off)[6],
+                                      uint32_t lds_byte) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %8, %2\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %9, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %10, %4\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %11, %5\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %12, %6\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %13, %7\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_byte), "s"(base[0]), "s"(base[1]), "s"(base[2]), "s"(base[3]),
+          "s"(base[4]), "s"(base[5]), "v"(off[0]), "v"(off[1]), "v"(off[2]),
+          "v"(off[3]), "v"(off[4]), "v"(off[5])
+        : "memory", "scc");
+}
+
+__device__ __forceinline__ void raw_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[BCELL_LDS];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    // wave index as a scalar: role branches and LDS-DMA bases stay on the SALU
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware tile map: blocks are dealt round-robin over the 8 XCDs, so
     // blockIdx % 8 names the blocks that share an L2.  Each XCD gets one
     // rectangular region of the tile grid (1/4 of the column tiles x 1/2 of
@@ -277,64 +315,52 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
 
     if (wave >= 4) {
         // ---------------- loader waves ----------------
-        const int lt = tid - 256;
-        const float *ap[2], *wp[4];
+        // wave lw issues instructions 6*lw .. 6*lw+5 of a chunk; instruction q
+        // fills stage rows 4q .. 4q+3 (rows 0-31: dgates, 32-95: weights);
+        // lane -> (row 4q + lane/16, granule slot lane%16)
+        const int lw = wave - 4;
+        const char *gb = (const char *)a.dgates, *wb = (const char *)a.wpackT;
+        uint32_t off[6];
+        bool is_a[6];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = lt + 256 * i;
-            const int row = idx >> 4, q = idx & 15;
-            // rows past the batch re-read the last row (never stored)
-            const int b = min(b0 + row, a.B - 1);
-            ap[i] = a.dgates + (long long)b * 4 * H + q * 4;
+        for (int i = 0; i < 6; ++i) {
+            const int q = lw * 6 + i;
+            const int row = 4 * q + (lane >> 4);
+            const int g = (lane & 15) ^ (row & 15);   // source granule (swizzle)
+            is_a[i] = q < BCM / 4;
+            if (is_a[i]) {
+                // rows past the batch re-read the last row (never stored)
+                const int b = min(b0 + row, a.B - 1);
+                off[i] = (uint32_t)(b * 4 * H + g * 4) * 4u;
+            } else {
+                off[i] = (uint32_t)((n0 + row - BCM) * K3 + g * 4) * 4u;
+            }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = lt + 256 * i;
-            const int row = idx >> 4, q = idx & 15;  // row 0..63
-            wp[i] = a.wpackT + (long long)(n0 + row) * K3 + q * 4;
-        }
-        f32x4 ra[4][2], rw[4][4];
-        auto load_chunk = [&](int c, f32x4 (&qa)[2], f32x4 (&qw)[4]) {
-            const int kb = min(c, last) * BCK;
+        const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(size_t)(__attribute__((address_space(3))) void *)lds);
+        auto issue = [&](int cc) {
+            const int kb = min(cc, last) * BCK;  // the tail re-reads the last chunk
             // dgates columns: [0,2H) shared; third segment dni at 2H, dnh at 3H
             const int acol = (kb >= 2 * H && hidden_side) ? kb + H : kb;
+            const char *base[6];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) qa[i] = *(const f32x4 *)(ap[i] + acol);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) qw[i] = *(const f32x4 *)(wp[i] + kb);
+            for (int i = 0; i < 6; ++i)
+                base[i] = is_a[i] ? gb + acol * 4 : wb + kb * 4;
+            glds6(base, off,
+                  lds0 + ((cc & (BNSTAGE - 1)) * BSTAGE + lw * 6 * 256) * 4u);
         };
-        auto store_chunk = [&](int stage, const f32x4 (&qa)[2],
-                               const f32x4 (&qw)[4]) {
-            float *As = lds + stage * BSTAGE;
-            float *Ws = As + BA_TILE;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = lt + 256 * i;
-                *(f32x4 *)(As + (idx >> 4) * BLDT + (idx & 15) * 4) = qa[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = lt + 256 * i;
-                *(f32x4 *)(Ws + (idx >> 4) * BLDT + (idx & 15) * 4) = qw[i];
-            }
-        };
-#pragma unroll
-        for (int i = 0; i < 4; ++i) load_chunk(i, ra[i], rw[i]);
-        store_chunk(0, ra[0], rw[0]);
-        load_chunk(4, ra[0], rw[0]);
-        store_chunk(1, ra[1], rw[1]);
-        load_chunk(5, ra[1], rw[1]);
-        __syncthreads();  // barrier #0: stages 0 and 1 are ready
-        int stage = 2;    // stage of chunk c + 2
-        for (int c = 0; c < npad; c += 4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                store_chunk(stage, ra[(i + 2) & 3], rw[(i + 2) & 3]);
-                load_chunk(c + i + 6, ra[(i + 2) & 3], rw[(i + 2) & 3]);
-                stage = stage == BNSTAGE - 1 ? 0 : stage + 1;
-                __syncthreads();
-            }
+        issue(0); issue(1); issue(2); issue(3);
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // chunks 0, 1 landed
+        raw_barrier();                                      // barrier #0
+        raw_barrier();  // #0b: the consumers hold chunk 0's fragments
+        for (int k = 0; k < npad; ++k) {
+            // stage of chunk k is free: its fragments were read before the
+            // barrier that ended iteration k - 1
+            issue(k + 4);
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // chunk k+2 landed
+            raw_barrier();
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         // ---------------- consumer waves ----------------
         // epilogue prefetch: element e = tid + 256 q -> tile e >> 10, row
@@ -365,17 +391,21 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
                 }
             }
         }
-        const int koff = wave * 16 + 4 * lh;
+        // this wave's 16-wide k slice; lane half lh supplies k = 8s + 4*lh + e,
+        // i.e. granule 4*wave + lh + 2s of its row, stored at slot ^ (row & 15)
+        int slot[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            slot[s] = lrow * BCK + (((4 * wave + lh + 2 * s) ^ (lrow & 15)) << 2);
         f32x4 fa0[2], fb0[2], fc0[2], fa1[2], fb1[2], fc1[2];
-        auto read_frags = [&](int stage, f32x4 (&fa)[2], f32x4 (&f0)[2],
+        auto read_frags = [&](int cc, f32x4 (&fa)[2], f32x4 (&f0)[2],
                               f32x4 (&f1)[2]) {
-            const float *As = lds + stage * BSTAGE;
-            const float *Ws = As + BA_TILE;
+            const float *As = lds + (cc & (BNSTAGE - 1)) * BSTAGE;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                fa[s] = *(const f32x4 *)(As + lrow * BLDT + koff + 8 * s);
-                f0[s] = *(const f32x4 *)(Ws + lrow * BLDT + koff + 8 * s);
-                f1[s] = *(const f32x4 *)(Ws + (32 + lrow) * BLDT + koff + 8 * s);
+                fa[s] = *(const f32x4 *)(As + slot[s]);
+                f0[s] = *(const f32x4 *)(As + BCM * BCK + slot[s]);
+                f1[s] = *(const f32x4 *)(As + (BCM + 32) * BCK + slot[s]);
             }
         };
         auto mfma_chunk = [&](const f32x4 (&fa)[2], const f32x4 (&f0)[2],
@@ -390,18 +420,16 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
                         fa[s][e], f1[s][e], acc1, 0, 0, 0);
                 }
         };
-        __syncthreads();  // barrier #0
+        raw_barrier();  // barrier #0
         read_frags(0, fa0, fb0, fc0);
-        int stage = 1;    // stage of chunk c + 1
+        raw_barrier();  // #0b: stage 0 may be refilled from here on
         for (int c = 0; c < npad; c += 2) {
-            read_frags(stage, fa1, fb1, fc1);   // prefetch chunk c + 1
+            read_frags(c + 1, fa1, fb1, fc1);   // prefetch chunk c + 1
             if (c < nchunks) mfma_chunk(fa0, fb0, fc0);
-            stage = stage == BNSTAGE - 1 ? 0 : stage + 1;
-            __syncthreads();
-            read_frags(stage, fa0, fb0, fc0);   // prefetch chunk c + 2
+            raw_barrier();
+            read_frags(c + 2, fa0, fb0, fc0);   // prefetch chunk c + 2
             if (c + 1 < nchunks) mfma_chunk(fa1, fb1, fc1);
-            stage = stage == BNSTAGE - 1 ? 0 : stage + 1;
-            __syncthreads();
+            raw_barrier();
         }
     }
 

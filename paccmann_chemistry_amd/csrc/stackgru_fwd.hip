@@ -17,249 +17,21 @@ namespace {
 // fused GRU cell
 // ------------------------------------------------------------------------------
 constexpr int CK = 64;        // K per chunk
-constexpr int LDT = CK + 4;   // LDS row stride in floats (272 B: conflict-free b128)
 constexpr int CM = 32;        // batch rows per block
 constexpr int CN = 32;        // hidden units per block (x3 gates)
-constexpr int A_TILE = CM * LDT;
-constexpr int W_TILE = 3 * CN * LDT;
-constexpr int STAGE = A_TILE + W_TILE;     // floats per LDS stage (34816 B)
-constexpr int NSTAGE = 3;
-constexpr int CELL_LDS = NSTAGE * STAGE;   // 104448 B
-static_assert(CELL_LDS >= 4 * 4 * 1024, "reduction buffer must fit");
 
 // Wave-specialised: waves 0-3 ("consumers", one per SIMD) only read operand
-// fragments from LDS and issue MFMAs; waves 4-7 ("loaders", the SIMD partners)
-// stream the operand chunks global -> registers -> LDS two chunks ahead.  One
-// workgroup barrier per chunk hands stage c+2 to the consumers, which prefetch
-// the fragments of chunk c+1 while the MFMAs of chunk c run, so global-load
-// latency, ds_write and ds_read all sit in the shadow of the matrix pipe.
-__global__ __launch_bounds__(512) void gru_cell_fwd_kernel(CellFwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[CELL_LDS];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int j0 = blockIdx.x * CN;   // first hidden unit of the tile
-    const int b0 = blockIdx.y * CM;   // first batch row
-    const int nchunks = a.nx_chunks + a.nh_chunks;
-    const int last = nchunks - 1;
-    const int npad = (nchunks + 3) & ~3;  // both roles run npad barriers
-    const int lrow = lane & 31, lh = lane >> 5;
-
-    f32x16 acc_r, acc_z, acc_ni, acc_nh;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        acc_r[r] = 0.f; acc_z[r] = 0.f; acc_ni[r] = 0.f; acc_nh[r] = 0.f;
-    }
-
-    if (wave >= 4) {
-        // ---------------- loader waves ----------------
-        const int lt = tid - 256;
-        // uniform base pointer (SGPRs, advanced per chunk on the scalar unit)
-        // + a fixed 32-bit byte offset per thread: the loads need no vector
-        // address arithmetic inside the loop
-        const char *xb = (const char *)a.xin, *hb = (const char *)a.hprev;
-        const char *wb = (const char *)a.wpack;
-        uint32_t offx[2], offh[2], offw[6];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = lt + 256 * i;
-            const int row = idx >> 4, q = idx & 15;
-            // rows past the batch re-read the last row (never stored)
-            const int b = min(b0 + row, a.B - 1);
-            offx[i] = (uint32_t)(b * a.ldx + q * 4) * 4u;
-            offh[i] = (uint32_t)(b * a.Hp + q * 4) * 4u;
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int idx = lt + 256 * i;
-            const int row = idx >> 4, q = idx & 15;  // row 0..95
-            const int g = row >> 5, jj = row & 31;
-            offw[i] = (uint32_t)((g * a.Hn + j0 + jj) * a.Kp + q * 4) * 4u;
-        }
-        // FOUR staging register sets: a chunk's loads are issued 4-6 chunks
-        // before its data is needed (128 KB in flight per CU), which is what
-        // the loaded-L2 latency asks for.  Loads are unconditional (the tail
-        // re-reads the last chunk) and the loop runs a whole number of groups
-        // of 4, so the body is straight-line and hipcc emits exact vmcnt(N).
-        f32x4 ra[4][2], rw[4][6];
-        auto load_chunk = [&](int c, f32x4 (&qa)[2], f32x4 (&qw)[6]) {
-            c = min(c, last);
-            const bool xpart = c < a.nx_chunks;
-            const int kb = (xpart ? c : c - a.nx_chunks) * (CK * 4);
-            const char *ab = (xpart ? xb : hb) + kb;
-            const char *wc = wb + c * (CK * 4);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                qa[i] = *(const f32x4 *)(ab + (xpart ? offx[i] : offh[i]));
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-                qw[i] = *(const f32x4 *)(wc + offw[i]);
-        };
-        auto store_chunk = [&](int stage, const f32x4 (&qa)[2],
-                               const f32x4 (&qw)[6]) {
-            float *As = lds + stage * STAGE;
-            float *Ws = As + A_TILE;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = lt + 256 * i;
-                *(f32x4 *)(As + (idx >> 4) * LDT + (idx & 15) * 4) = qa[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int idx = lt + 256 * i;
-                *(f32x4 *)(Ws + (idx >> 4) * LDT + (idx & 15) * 4) = qw[i];
-            }
-        };
-#pragma unroll
-        for (int i = 0; i < 4; ++i) load_chunk(i, ra[i], rw[i]);
-        store_chunk(0, ra[0], rw[0]);
-        load_chunk(4, ra[0], rw[0]);
-        store_chunk(1, ra[1], rw[1]);
-        load_chunk(5, ra[1], rw[1]);
-        __syncthreads();  // barrier #0: stages 0 and 1 are ready
-        int stage = 2;    // stage of chunk c + 2
-        for (int c = 0; c < npad; c += 4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                // chunk c + i + 2 lives in register set (i + 2) & 3
-                store_chunk(stage, ra[(i + 2) & 3], rw[(i + 2) & 3]);
-                load_chunk(c + i + 6, ra[(i + 2) & 3], rw[(i + 2) & 3]);
-                stage = stage == NSTAGE - 1 ? 0 : stage + 1;
-                __syncthreads();
-            }
-        }
-    } else {
-        // ---------------- consumer waves ----------------
-        // this wave's 16-wide k slice; lane half lh supplies k = 8s + 4*lh + e
-        const int koff = wave * 16 + 4 * lh;
-        f32x4 fa0[2], fr0[2], fz0[2], fn0[2];
-        f32x4 fa1[2], fr1[2], fz1[2], fn1[2];
-        auto read_frags = [&](int stage, f32x4 (&fa)[2], f32x4 (&fr)[2],
-                              f32x4 (&fz)[2], f32x4 (&fn)[2]) {
-            const float *As = lds + stage * STAGE;
-            const float *Ws = As + A_TILE;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                fa[s] = *(const f32x4 *)(As + lrow * LDT + koff + 8 * s);
-                fr[s] = *(const f32x4 *)(Ws + (0 * CN + lrow) * LDT + koff + 8 * s);
-                fz[s] = *(const f32x4 *)(Ws + (1 * CN + lrow) * LDT + koff + 8 * s);
-                fn[s] = *(const f32x4 *)(Ws + (2 * CN + lrow) * LDT + koff + 8 * s);
-            }
-        };
-        auto mfma_chunk = [&](int c, const f32x4 (&fa)[2], const f32x4 (&fr)[2],
-                              const f32x4 (&fz)[2], const f32x4 (&fn)[2]) {
-            if (c < a.nx_chunks) {
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            fa[s][e], fr[s][e], acc_r, 0, 0, 0);
-                        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            fa[s][e], fz[s][e], acc_z, 0, 0, 0);
-                        acc_ni = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            fa[s][e], fn[s][e], acc_ni, 0, 0, 0);
-                    }
-            } else {
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            fa[s][e], fr[s][e], acc_r, 0, 0, 0);
-                        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            fa[s][e], fz[s][e], acc_z, 0, 0, 0);
-                        acc_nh = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            fa[s][e], fn[s][e], acc_nh, 0, 0, 0);
-                    }
-            }
-        };
-        __syncthreads();  // barrier #0
-        read_frags(0, fa0, fr0, fz0, fn0);
-        int stage = 1;    // stage of chunk c + 1
-        for (int c = 0; c < npad; c += 2) {
-            read_frags(stage, fa1, fr1, fz1, fn1);   // prefetch chunk c + 1
-            if (c < nchunks) mfma_chunk(c, fa0, fr0, fz0, fn0);
-            stage = stage == NSTAGE - 1 ? 0 : stage + 1;
-            __syncthreads();
-            read_frags(stage, fa0, fr0, fz0, fn0);   // prefetch chunk c + 2
-            if (c + 1 < nchunks) mfma_chunk(c + 1, fa1, fr1, fz1, fn1);
-            stage = stage == NSTAGE - 1 ? 0 : stage + 1;
-            __syncthreads();
-        }
-    }
-
-    // cross-wave reduction of the 4 partial tiles through LDS
-    __syncthreads();
-    float *red = lds;  // [wave][tile][32][32]
-    if (wave < 4) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            float *base = red + (wave * 4) * 1024 + row * 32 + lrow;
-            base[0 * 1024] = acc_r[r];
-            base[1 * 1024] = acc_z[r];
-            base[2 * 1024] = acc_ni[r];
-            base[3 * 1024] = acc_nh[r];
-        }
-    }
-    __syncthreads();
-
-    const int H = a.H, Hn = a.Hn;
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int e = tid + 512 * q;
-        const int row = e >> 5, col = e & 31;
-        const int b = b0 + row, j = j0 + col;
-        float s[4];
-#pragma unroll
-        for (int tl = 0; tl < 4; ++tl) {
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) v += red[(w * 4 + tl) * 1024 + e];
-            s[tl] = v;
-        }
-        if (b >= a.B || j >= H) continue;
-        float tr = 0.f, tz = 0.f, tn = 0.f;
-        if (a.tokg) {
-            long long tk = a.tok[b];
-            if (tk < 0 || tk >= a.V) {
-                tk = tk < 0 ? 0 : a.V - 1;
-                if (a.status) atomicOr(a.status, PCM_STATUS_BAD_TOKEN);
-            }
-            const float *tg = a.tokg + tk * (3LL * Hn);
-            tr = tg[j]; tz = tg[Hn + j]; tn = tg[2 * Hn + j];
-        }
-        const float r_ = pcm_sigmoid(s[0] + a.bpack[j] + tr);
-        const float z_ = pcm_sigmoid(s[1] + a.bpack[Hn + j] + tz);
-        const float ghn = s[3] + a.bpack[3 * Hn + j];
-        const float n_ = tanhf(s[2] + a.bpack[2 * Hn + j] + tn + r_ * ghn);
-        const float hp = a.hprev[(long long)b * a.Hp + j];
-        // ATen GRU cell: (h - n) * z + n
-        float hn = __fadd_rn(__fmul_rn(hp - n_, z_), n_);
-        if (a.lengths && a.t >= a.lengths[b]) hn = hp;
-        a.hnew[(long long)b * a.Hp + j] = hn;
-        if (a.gates) {
-            float *g = a.gates + (long long)b * 4 * H;
-            g[j] = r_; g[H + j] = z_; g[2 * H + j] = n_; g[3 * H + j] = ghn;
-        }
-        if (a.xdrop)
-            a.xdrop[(long long)b * a.Hp + j] =
-                hn * pcm_dropout_scale(a.seed, a.next_layer, a.t, b, j,
-                                       a.drop_p, a.inv_keep);
-    }
-}
-
-// ------------------------------------------------------------------------------
-// The same cell with LDS-DMA staging (global_load_lds_dwordx4): the loader waves
-// issue loads that land in LDS directly -- no staging registers, no ds_write
-// pass, no vector address arithmetic.  An LDS-DMA wave instruction writes 1 KiB
-// lane-linear, so rows are unpadded (256 B) and bank conflicts are avoided by an
-// XOR swizzle of the 16-byte granule index with (row & 15), applied on the
-// SOURCE address by the loaders and on the LDS address by the consumers.
-// Four 32 KiB stages; the loaders keep two chunks in flight across each raw
-// s_barrier (counted vmcnt, never __syncthreads inside the loop, which would
-// drain the DMA queue).
-// ------------------------------------------------------------------------------
+// fragments from LDS and issue MFMAs, each owning a 16-wide k slice of every
+// 64-wide chunk (intra-block split-K, LDS reduce at the end); waves 4-7
+// ("loaders", the SIMD partners) stream the chunks with LDS-DMA loads
+// (global_load_lds_dwordx4) that land in LDS directly -- no staging registers,
+// no ds_write pass, no vector address arithmetic.  An LDS-DMA wave instruction
+// writes 1 KiB lane-linear, so rows are unpadded (256 B) and bank conflicts are
+// avoided by an XOR swizzle of the 16-byte granule index with (row & 15),
+// applied on the SOURCE address by the loaders and on the LDS address by the
+// consumers.  Four 32 KiB stages; the loaders keep two chunks in flight across
+// each raw s_barrier (counted vmcnt, never __syncthreads inside the loop, which
+// would drain the DMA queue).
 constexpr int GSTAGE = (CM + 3 * CN) * CK;   // floats per stage (32 KiB)
 constexpr int GNSTAGE = 4;
 constexpr int GCELL_LDS = GNSTAGE * GSTAGE;  // 128 KiB
@@ -311,7 +83,7 @@ __device__ __forceinline__ void raw_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
-__global__ __launch_bounds__(512) void gru_cell_fwd_glds_kernel(CellFwdArgs a) {
+__global__ __launch_bounds__(512) void gru_cell_fwd_kernel(CellFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[GCELL_LDS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -851,12 +623,7 @@ int grid_for(long long n) {
 
 int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
     dim3 grid(a.Hn / CN, (a.B + CM - 1) / CM);
-    static const bool glds = getenv("PCM_CELL_GLDS") != nullptr;
-    if (glds)
-        hipLaunchKernelGGL(gru_cell_fwd_glds_kernel, grid, dim3(512), 0, stream,
-                           a);
-    else
-        hipLaunchKernelGGL(gru_cell_fwd_kernel, grid, dim3(512), 0, stream, a);
+    hipLaunchKernelGGL(gru_cell_fwd_kernel, grid, dim3(512), 0, stream, a);
     return 0;
 }
 
