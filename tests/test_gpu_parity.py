@@ -382,6 +382,47 @@ def test_full_batch_rows_match_small_batch():
     assert torch.isfinite(loss).item()
 
 
+def test_long_reduction_gradients_match_oracle():
+    """Config-shaped model at batch 32 x 120 steps: the weight gradients sum
+    over 3840 rows, which takes the K-major GEMM through its split-K slabs,
+    the folded bias column sums and the narrow (skinny) wave mappings.  Every
+    parameter gradient against the oracle's autograd."""
+    from paccmann_chemistry_amd import vae_loss_function
+    p = {
+        'latent_dim': 256, 'rnn_cell_size': 512, 'embedding_size': 60,
+        'vocab_size': 60, 'stack_width': 50, 'stack_depth': 50, 'n_layers': 2,
+        'dropout': 0.0, 'batch_size': 32, 'batch_mode': 'padded',
+        'embedding': 'one_hot', 'use_stack': True, 'bidirectional': False
+    }
+    seq_len = 120
+    sd = W.make_state_dict(p, 311)
+    tokens = W.synthetic_tokens(seq_len, 32, 60, 12)
+    targets = W.shifted_targets(tokens)
+    eps = torch.from_numpy(np.random.default_rng(5).standard_normal(
+        (32, 256)).astype(np.float32))
+    vae = _build_vae(p, sd)
+    dev = _dev()
+    dec_loss, mu, logvar = vae(tokens.to(dev), tokens.to(dev), targets.to(dev),
+                               eps=eps.to(dev))
+    total, _ = vae_loss_function(dec_loss, mu, logvar, kl_growth=0.003,
+                                 step=5000)
+    total.backward()
+    ref = {k: v.clone().requires_grad_('embedding' not in k)
+           for k, v in sd.items()}
+    r_loss, r_mu, r_logvar, _, _ = O.vae_forward(
+        ref, tokens, tokens, targets, eps, p['stack_depth'])
+    r_total, _ = O.vae_loss(r_loss, r_mu, r_logvar, 0.003, step=5000)
+    r_total.backward()
+    assert abs(total.item() - r_total.item()) < 1e-5 * abs(r_total.item())
+    worst = {}
+    for name, param in vae.named_parameters():
+        if ref[name].grad is None:
+            continue
+        worst[name] = _rel_to_max(param.grad, ref[name].grad)
+    bad = {k: v for k, v in worst.items() if not v < GRAD_TOL}
+    assert not bad, bad
+
+
 def test_sampling_search_distribution():
     """SamplingSearch.step (search.py:124-141): device draws follow
     softmax(logits / T); checked through generation statistics."""
