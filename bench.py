@@ -234,7 +234,7 @@ def main():
                           'timed step, minus the empty-bracket reading',
             }
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(p, args.cpu_batch)
         line = {
             'metric': 'SMILES tokens/sec (train fwd+bwd)',
