@@ -153,8 +153,9 @@ def main():
     dec_tokens[(keep == 0).to(dev)] = 1
 
     buckets = dp.GradientBuckets(vae, overlap=world > 1)
-    params = [q for q in vae.parameters() if q.requires_grad]
-    optimizer = torch.optim.Adam(params, lr=LR)
+    # torch.optim.Adam's update (training.py:132) as one fused launch per
+    # flat bucket (tests/test_gpu_parity.py: test_flat_adam_matches_torch_adam)
+    optimizer = dp.FlatAdam(buckets, lr=LR)
     lib = _lib.load()
 
     def step(global_step):

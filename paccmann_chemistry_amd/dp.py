@@ -32,9 +32,9 @@ def scale_losses(decoder_loss, kl_div, kl_w):
 class GradientBuckets:
     """Flat gradient buckets of a TeacherVAE, reduced with async all-reduce.
 
-    Parameters are re-pointed into one flat buffer per bucket so that a
-    bucket's gradients are contiguous: ``param.grad`` becomes a view of the
-    flat gradient buffer and no flatten/unflatten copies are needed."""
+    ``param.grad`` of every parameter is a view of its bucket's flat gradient
+    buffer, so a bucket's gradients are contiguous and no flatten / unflatten
+    copies are needed (FlatAdam below does the same for the parameters)."""
 
     def __init__(self, model, overlap=True):
         self.model = model
@@ -118,3 +118,47 @@ class GradientBuckets:
             bucket['ready'] = 0
             for p, view in zip(bucket['params'], bucket['views']):
                 p.grad = view
+
+
+class FlatAdam:
+    """``torch.optim.Adam`` (betas, eps as given, no weight decay / amsgrad --
+    the reference's ``OPTIMIZER_FACTORY['adam'](params, lr=lr)``,
+    training.py:132) over the flat buffers of a GradientBuckets: the
+    parameters are re-pointed into one flat buffer per bucket and a step is one
+    ``pcm_adam_step`` launch per bucket instead of a multi-tensor sweep."""
+
+    def __init__(self, buckets, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.buckets = buckets
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.step_count = 0
+        self.state = []
+        for bucket in buckets.buckets:
+            if bucket is None:
+                self.state.append(None)
+                continue
+            flat = torch.empty_like(bucket['flat'])
+            off = 0
+            with torch.no_grad():
+                for p in bucket['params']:
+                    view = flat[off:off + p.numel()].view_as(p)
+                    view.copy_(p.data)
+                    p.data = view
+                    off += p.numel()
+            self.state.append({
+                'param': flat,
+                'exp_avg': torch.zeros_like(flat),
+                'exp_avg_sq': torch.zeros_like(flat),
+            })
+
+    def zero_grad(self):
+        self.buckets.zero_grad()
+
+    def step(self):
+        from .ops import adam_step
+        self.step_count += 1
+        for bucket, st in zip(self.buckets.buckets, self.state):
+            if bucket is None:
+                continue
+            adam_step(st['param'], bucket['flat'], st['exp_avg'],
+                      st['exp_avg_sq'], self.lr, self.betas[0], self.betas[1],
+                      self.eps, self.step_count)
