@@ -162,3 +162,60 @@ def crop_start(smiles, smiles_language):
         return smiles[start_idx + 1:]
     except Exception:
         return smiles
+
+
+def packed_to_padded(seq, target_packed=None):
+    """utils/utils.py:171-203: per-step outputs of a packed run (``seq[t]``
+    holds one token per sequence still active at step t) -> f32[B, T] padded
+    with 0.  The reference derives the finished rows from STOP tokens in the
+    packed target; with the length-sorted layout its loops assume, the active
+    rows of step t are simply the first ``len(seq[t])`` ones, which is what is
+    used here (``target_packed`` is accepted for signature compatibility)."""
+    steps = len(seq)
+    batch_size = len(seq[0])
+    padded = torch.zeros(batch_size, steps)
+    for t in range(steps):
+        row = torch.as_tensor(seq[t]).reshape(-1)
+        padded[:row.numel(), t] = row.to(padded.dtype)
+    return padded
+
+
+def print_example_reconstruction(
+    reconstruction, inp, language, selfies=False, crop_stop=True
+):
+    """utils/utils.py:302-343: (target text, reconstructed text) of one random
+    sample.  Any language object with ``token_indexes_to_smiles`` (or
+    ``token_indexes_to_sequence``) is accepted -- pytoda is not a dependency."""
+    if hasattr(language, 'token_indexes_to_smiles'):
+        to_text = language.token_indexes_to_smiles
+        if selfies and hasattr(language, 'selfies_to_smiles'):
+            inner = to_text
+
+            def to_text(tokens):
+                return language.selfies_to_smiles(inner(tokens))
+    elif hasattr(language, 'token_indexes_to_sequence'):
+        to_text = language.token_indexes_to_sequence
+    else:
+        raise TypeError(f'Unknown language class: {type(language)}')
+    import numpy as np
+    sample_idx = np.random.randint(len(reconstruction))
+    crop = crop_start_stop if crop_stop else crop_start
+    reconstructed = crop(torch.as_tensor(reconstruction[sample_idx]).long(),
+                         language)
+    if isinstance(inp, torch.Tensor):
+        inp = inp.permute(1, 0)
+    elif not isinstance(inp, list):
+        raise TypeError(f'Unknown input type {type(inp)}')
+    sample = torch.as_tensor(inp[sample_idx]).tolist()
+    return to_text(sample), to_text(reconstructed)
+
+
+def disable_rdkit_logging():
+    """utils/utils.py:346-352; a no-op when rdkit is not installed."""
+    try:
+        import rdkit.RDLogger as rkl
+        import rdkit.rdBase as rkrb
+    except ImportError:
+        return
+    rkl.logger().setLevel(rkl.ERROR)
+    rkrb.DisableLog('rdApp.error')

@@ -219,3 +219,41 @@ def test_kl_weight_and_factories():
     assert sorted(OPTIMIZER_FACTORY) == [
         'adadelta', 'adagrad', 'adam', 'adamax', 'rmsprop', 'sgd'
     ]
+
+
+def test_reference_import_paths_resolve():
+    """Code written against the reference's package layout
+    (examples/train_vae.py:9-16, generate_latent_codes.py:9-15) imports the
+    MI355X implementation through the compatibility package."""
+    import subprocess
+    import sys
+    code = (
+        'from paccmann_chemistry.utils import (collate_fn, get_device, '
+        'disable_rdkit_logging, sequential_data_preparation, '
+        'packed_sequential_data_preparation, kl_weight, packed_to_padded)\n'
+        'from paccmann_chemistry.models.vae import (StackGRUDecoder, '
+        'StackGRUEncoder, TeacherVAE)\n'
+        'from paccmann_chemistry.models import StackGRU\n'
+        'from paccmann_chemistry.models.training import train_vae, test_vae\n'
+        'from paccmann_chemistry.utils.hyperparams import SEARCH_FACTORY, '
+        'OPTIMIZER_FACTORY\n'
+        'from paccmann_chemistry.utils.search import GreedySearch\n'
+        'from paccmann_chemistry.utils.loss_functions import '
+        'vae_loss_function\n'
+        'import paccmann_chemistry_amd as P\n'
+        'assert TeacherVAE is P.TeacherVAE and StackGRU is P.StackGRU\n'
+        'disable_rdkit_logging()\n'
+        'print("ok")\n'
+    )
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, '-c', code], cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == 'ok'
+
+
+def test_packed_to_padded_sorted_batch():
+    from paccmann_chemistry_amd.utils import packed_to_padded
+    seq = [torch.tensor([5, 6, 7]), torch.tensor([8, 9]), torch.tensor([4])]
+    out = packed_to_padded(seq, [])
+    assert out.tolist() == [[5.0, 8.0, 4.0], [6.0, 9.0, 0.0], [7.0, 0.0, 0.0]]
