@@ -423,6 +423,105 @@ def test_long_reduction_gradients_match_oracle():
     assert not bad, bad
 
 
+SWEEP = {
+    # name: (params overrides, T, ragged lengths?)
+    'h192_l3_learned_packed': (dict(
+        rnn_cell_size=192, n_layers=3, stack_width=33, stack_depth=9,
+        vocab_size=37, embedding_size=20, embedding='learned', latent_dim=40,
+        batch_size=37, batch_mode='packed'), 11, True),
+    'h1024_l1_nostack': (dict(
+        rnn_cell_size=1024, n_layers=1, vocab_size=24, embedding_size=24,
+        latent_dim=48, batch_size=64, use_stack=False), 6, False),
+    'h1024_l2_stack': (dict(
+        rnn_cell_size=1024, n_layers=2, stack_width=20, stack_depth=7,
+        vocab_size=24, embedding_size=24, latent_dim=32, batch_size=40), 5,
+        False),
+    'h64_bidir_b200': (dict(
+        rnn_cell_size=64, n_layers=2, stack_width=12, stack_depth=6,
+        vocab_size=30, embedding_size=30, latent_dim=24, batch_size=200,
+        bidirectional=True), 7, False),
+    'h256_w64_b33_packed': (dict(
+        rnn_cell_size=256, n_layers=2, stack_width=64, stack_depth=4,
+        vocab_size=61, embedding_size=61, latent_dim=16, batch_size=33,
+        batch_mode='packed'), 9, True),
+    'h320_wide_stack': (dict(
+        rnn_cell_size=320, n_layers=2, stack_width=70, stack_depth=3,
+        vocab_size=28, embedding_size=28, latent_dim=16, batch_size=48), 4,
+        False),
+}
+
+
+@pytest.mark.parametrize('name', sorted(SWEEP))
+def test_shape_sweep_matches_oracle(name):
+    """Shapes off the tuned path (hidden sizes above 512 / not tile multiples,
+    deep, wide stacks, ragged packed batches, bidirectional, large batch):
+    loss, per-step logits and every parameter gradient against the oracle."""
+    from paccmann_chemistry_amd import vae_loss_function
+    over, seq_len, ragged = SWEEP[name]
+    p = {
+        'latent_dim': 16, 'rnn_cell_size': 32, 'embedding_size': 20,
+        'vocab_size': 20, 'stack_width': 5, 'stack_depth': 7, 'n_layers': 2,
+        'dropout': 0.0, 'batch_size': 4, 'batch_mode': 'padded',
+        'embedding': 'one_hot', 'use_stack': True, 'bidirectional': False
+    }
+    p.update(over)
+    batch = p['batch_size']
+    sd = W.make_state_dict(p, 900)
+    lengths = None
+    if ragged:
+        lengths = sorted(W.ragged_lengths(batch, seq_len, 901,
+                                          mean=seq_len * 0.6, std=3, lo=2),
+                         reverse=True)
+        lengths[0] = seq_len
+    tokens = W.synthetic_tokens(seq_len, batch, p['vocab_size'], 902, lengths)
+    targets = W.shifted_targets(tokens)
+    if lengths is not None:
+        for b, n in enumerate(lengths):
+            targets[n - 1:, b] = 0
+    eps = torch.from_numpy(np.random.default_rng(903).standard_normal(
+        (batch, p['latent_dim'])).astype(np.float32))
+    vae = _build_vae(p, sd)
+    dev = _dev()
+    if lengths is None:
+        enc = dec = tokens.to(dev)
+        tgt = targets.to(dev)
+    else:
+        pack = torch.nn.utils.rnn.pack_sequence
+        enc = dec = pack([tokens[:n, b].to(dev) for b, n in enumerate(lengths)])
+        tgt = pack([targets[:n, b].to(dev) for b, n in enumerate(lengths)])
+    dec_loss, mu, logvar = vae(enc, dec, tgt, eps=eps.to(dev))
+    total, _ = vae_loss_function(dec_loss, mu, logvar, kl_growth=0.003,
+                                 step=5000)
+    total.backward()
+    vae.check_tokens()
+
+    trainable = {k for k, q in vae.named_parameters() if q.requires_grad}
+    ref = {k: v.clone().requires_grad_(k in trainable) for k, v in sd.items()}
+    len_t = None if lengths is None else torch.tensor(lengths)
+    r_loss, r_mu, r_logvar, r_logits, _ = O.vae_forward(
+        ref, tokens, tokens, targets, eps, p['stack_depth'], len_t,
+        p['use_stack'], p['bidirectional'])
+    r_total, _ = O.vae_loss(r_loss, r_mu, r_logvar, 0.003, step=5000)
+    r_total.backward()
+    assert _rel_to_max(mu, r_mu) < 1e-5
+    logits = vae.decoder.logits
+    if lengths is not None:
+        active = (len_t.view(1, -1) > torch.arange(seq_len).view(-1, 1))
+        mask = active.unsqueeze(-1).to(logits.dtype)
+        assert _rel_to_max(logits.cpu() * mask, r_logits * mask) < LOGIT_TOL
+    else:
+        assert _rel_to_max(logits, r_logits) < LOGIT_TOL
+    assert abs(total.item() - r_total.item()) < 1e-5 * abs(r_total.item())
+    bad = {}
+    for key, param in vae.named_parameters():
+        if ref[key].grad is None:
+            continue
+        err = _rel_to_max(param.grad, ref[key].grad)
+        if not err < GRAD_TOL:
+            bad[key] = err
+    assert not bad, bad
+
+
 def test_flat_adam_matches_torch_adam():
     """dp.FlatAdam (one pcm_adam_step per flat bucket) against torch.optim.Adam
     on the same parameters and gradient sequence, 6 steps."""
