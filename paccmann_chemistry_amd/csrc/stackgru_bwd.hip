@@ -233,14 +233,14 @@ constexpr int BCK = 64;         // K per chunk
 constexpr int BCM = 32;         // batch rows per block
 constexpr int BCN = 64;         // output columns per block (2 MFMA tiles)
 constexpr int BSTAGE = (BCM + BCN) * BCK;   // floats per LDS stage (24 KiB)
-constexpr int BNSTAGE = 4;
-constexpr int BCELL_LDS = BNSTAGE * BSTAGE; // 96 KiB
+constexpr int BNSTAGE = 2;
+constexpr int BCELL_LDS = BNSTAGE * BSTAGE; // 48 KiB
 static_assert(BCELL_LDS >= 4 * 2 * 1024, "reduction buffer must fit");
 
 // Wave-specialised like the forward cell: waves 4-7 stream the operand chunks
 // into LDS with LDS-DMA loads (global_load_lds_dwordx4; unpadded 256-byte rows,
-// 16-byte granules XOR-swizzled with (row & 15) on the source address; four
-// stages, one chunk in flight across each raw barrier, hand-counted vmcnt),
+// 16-byte granules XOR-swizzled with (row & 15) on the source address; two
+// stages, one chunk in flight across the raw barriers, hand-counted vmcnt),
 // waves 0-3 read fragments and issue the MFMAs.  The consumer waves issue no
 // global loads inside the loop, so they fetch everything the epilogue needs
 // (running gradients, the lower layer's saved gates: cold HBM lines) at kernel
@@ -303,15 +303,45 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
     const bool hidden_side = n0 < H;   // tile of dh[l] (uses dnh) or of dx (dni)
     const int nchunks = K3 / BCK;
     const int last = nchunks - 1;
-    const int npad = (nchunks + 3) & ~3;  // both roles run npad barriers
     const int lrow = lane & 31, lh = lane >> 5;
 
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    // epilogue operands of this thread's 8 outputs (consumer waves only)
-    float pre_d[8], pre_r[8], pre_z[8], pre_n[8], pre_g[8], pre_h[8];
-    int pre_len[4];
+    // Epilogue operands of this thread's 4 outputs (element e = tid + 512 q ->
+    // tile e >> 10, row (e & 1023) >> 5, column e & 31), fetched before anything
+    // else: they are cold HBM lines (running gradients, the lower layer's saved
+    // gates) and with in-order vmcnt they are the oldest loads of either role,
+    // so their latency is paid once under the first chunk's DMA instead of at
+    // the end of the kernel.
+    float pre_d[4], pre_r[4], pre_z[4], pre_n[4], pre_g[4], pre_h[4];
+    int pre_len[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int b = min(b0 + (tid >> 5) + 16 * q, a.B - 1);
+        pre_len[q] = a.lengths ? a.lengths[b] : 0x7fffffff;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 512 * q;
+        const int tl = e >> 10, ee = e & 1023;
+        const int b = min(b0 + (ee >> 5), a.B - 1);
+        const int n = n0 + tl * 32 + (ee & 31);
+        pre_d[q] = pre_r[q] = pre_z[q] = pre_n[q] = pre_g[q] = pre_h[q] = 0.f;
+        if (hidden_side) {
+            pre_d[q] = a.dh[(long long)b * a.Hp + n];
+        } else {
+            const int j = min(n - H, a.dx_cols - 1);
+            if (a.gates_low || a.dx_accumulate)
+                pre_d[q] = a.dx[(long long)b * a.ldx + j];
+            if (a.gates_low) {
+                const float *g = a.gates_low + (long long)b * 4 * H;
+                pre_r[q] = g[j]; pre_z[q] = g[H + j];
+                pre_n[q] = g[2 * H + j]; pre_g[q] = g[3 * H + j];
+                pre_h[q] = a.hprev_low[(long long)b * a.Hp + j];
+            }
+        }
+    }
 
     if (wave >= 4) {
         // ---------------- loader waves ----------------
@@ -349,67 +379,36 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
             glds6(base, off,
                   lds0 + ((cc & (BNSTAGE - 1)) * BSTAGE + lw * 6 * 256) * 4u);
         };
-        issue(0); issue(1); issue(2); issue(3);
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // chunks 0, 1 landed
-        raw_barrier();                                      // barrier #0
-        raw_barrier();  // #0b: the consumers hold chunk 0's fragments
-        for (int k = 0; k < npad; ++k) {
-            // stage of chunk k is free: its fragments were read before the
-            // barrier that ended iteration k - 1
-            issue(k + 4);
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");  // chunk k+2 landed
-            raw_barrier();
+        issue(0); issue(1);
+        for (int k = 0; k < nchunks; ++k) {
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // chunk k landed
+            raw_barrier();   // A_k: the consumers may read chunk k
+            raw_barrier();   // B_k: they hold its fragments, the stage is free
+            issue(k + 2);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         // ---------------- consumer waves ----------------
-        // epilogue prefetch: element e = tid + 256 q -> tile e >> 10, row
-        // (e & 1023) >> 5, column e & 31 (the mapping of the reduction below)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int b = min(b0 + (tid >> 5) + 8 * q, a.B - 1);
-            pre_len[q] = a.lengths ? a.lengths[b] : 0x7fffffff;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = tid + 256 * q;
-            const int tl = e >> 10, ee = e & 1023;
-            const int b = min(b0 + (ee >> 5), a.B - 1);
-            const int n = n0 + tl * 32 + (ee & 31);
-            pre_d[q] = pre_r[q] = pre_z[q] = pre_n[q] = pre_g[q] = pre_h[q] = 0.f;
-            if (hidden_side) {
-                pre_d[q] = a.dh[(long long)b * a.Hp + n];
-            } else {
-                const int j = min(n - H, a.dx_cols - 1);
-                if (a.gates_low || a.dx_accumulate)
-                    pre_d[q] = a.dx[(long long)b * a.ldx + j];
-                if (a.gates_low) {
-                    const float *g = a.gates_low + (long long)b * 4 * H;
-                    pre_r[q] = g[j]; pre_z[q] = g[H + j];
-                    pre_n[q] = g[2 * H + j]; pre_g[q] = g[3 * H + j];
-                    pre_h[q] = a.hprev_low[(long long)b * a.Hp + j];
-                }
-            }
-        }
         // this wave's 16-wide k slice; lane half lh supplies k = 8s + 4*lh + e,
         // i.e. granule 4*wave + lh + 2s of its row, stored at slot ^ (row & 15)
         int slot[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
             slot[s] = lrow * BCK + (((4 * wave + lh + 2 * s) ^ (lrow & 15)) << 2);
-        f32x4 fa0[2], fb0[2], fc0[2], fa1[2], fb1[2], fc1[2];
-        auto read_frags = [&](int cc, f32x4 (&fa)[2], f32x4 (&f0)[2],
-                              f32x4 (&f1)[2]) {
-            const float *As = lds + (cc & (BNSTAGE - 1)) * BSTAGE;
+        // two barriers per chunk, one fragment set: a simpler, smaller kernel
+        // measured faster than the deeper pipeline (four stages, fragment
+        // double buffer) it replaced -- the MFMA loop is at its issue bound
+        for (int c = 0; c < nchunks; ++c) {
+            f32x4 fa[2], f0[2], f1[2];
+            raw_barrier();   // A_c
+            const float *As = lds + (c & (BNSTAGE - 1)) * BSTAGE;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 fa[s] = *(const f32x4 *)(As + slot[s]);
                 f0[s] = *(const f32x4 *)(As + BCM * BCK + slot[s]);
                 f1[s] = *(const f32x4 *)(As + (BCM + 32) * BCK + slot[s]);
             }
-        };
-        auto mfma_chunk = [&](const f32x4 (&fa)[2], const f32x4 (&f0)[2],
-                              const f32x4 (&f1)[2]) {
+            raw_barrier();   // B_c (waits for the fragment reads first)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -419,17 +418,6 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(
                         fa[s][e], f1[s][e], acc1, 0, 0, 0);
                 }
-        };
-        raw_barrier();  // barrier #0
-        read_frags(0, fa0, fb0, fc0);
-        raw_barrier();  // #0b: stage 0 may be refilled from here on
-        for (int c = 0; c < npad; c += 2) {
-            read_frags(c + 1, fa1, fb1, fc1);   // prefetch chunk c + 1
-            if (c < nchunks) mfma_chunk(fa0, fb0, fc0);
-            raw_barrier();
-            read_frags(c + 2, fa0, fb0, fc0);   // prefetch chunk c + 2
-            if (c + 1 < nchunks) mfma_chunk(fa1, fb1, fc1);
-            raw_barrier();
         }
     }
 
@@ -445,11 +433,10 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
         }
     }
     __syncthreads();
-    if (wave >= 4) return;
 
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int e = tid + 256 * q;       // 0..2047
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + 512 * q;       // 0..2047
         const int tl = e >> 10, ee = e & 1023;
         const int row = ee >> 5, col = ee & 31;
         float v = 0.f;
@@ -471,7 +458,7 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
                 // derivatives right here (saves a launch per step)
                 const float d = pre_d[q] + v;
                 float *g = a.gates_low + (long long)b * 4 * H;
-                if (a.t >= pre_len[q & 3]) {
+                if (a.t >= pre_len[q & 1]) {
                     g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f;
                     g[3 * H + j] = 0.f;
                     *dst = d;

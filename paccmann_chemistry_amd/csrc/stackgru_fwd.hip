@@ -29,13 +29,10 @@ constexpr int CN = 32;        // hidden units per block (x3 gates)
 // writes 1 KiB lane-linear, so rows are unpadded (256 B) and bank conflicts are
 // avoided by an XOR swizzle of the 16-byte granule index with (row & 15),
 // applied on the SOURCE address by the loaders and on the LDS address by the
-// consumers.  Four 32 KiB stages; the loaders keep two chunks in flight across
-// each raw s_barrier (counted vmcnt, never __syncthreads inside the loop, which
-// would drain the DMA queue).
+// consumers.  The loaders keep one chunk in flight across the raw s_barriers
+// (counted vmcnt, never __syncthreads inside the loop, which would drain the
+// DMA queue).
 constexpr int GSTAGE = (CM + 3 * CN) * CK;   // floats per stage (32 KiB)
-constexpr int GNSTAGE = 4;
-constexpr int GCELL_LDS = GNSTAGE * GSTAGE;  // 128 KiB
-static_assert(GCELL_LDS >= 4 * 4 * 1024, "reduction buffer must fit");
 
 // Eight LDS-DMA loads of one loader wave: lane offsets off[i] (bytes) from the
 // uniform base, destinations lds_byte + 1 KiB * i.  Inline asm on purpose: hipcc
@@ -83,138 +80,15 @@ __device__ __forceinline__ void raw_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
-__global__ __launch_bounds__(512) void gru_cell_fwd_kernel(CellFwdArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[GCELL_LDS];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    // wave index as a scalar: role branches and LDS-DMA bases stay on the SALU
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int j0 = blockIdx.x * CN;   // first hidden unit of the tile
-    const int b0 = blockIdx.y * CM;   // first batch row
-    const int nchunks = a.nx_chunks + a.nh_chunks;
-    const int last = nchunks - 1;
-    const int npad = (nchunks + 3) & ~3;  // both roles run npad barriers
-    const int lrow = lane & 31, lh = lane >> 5;
-
-    f32x16 acc_r, acc_z, acc_ni, acc_nh;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        acc_r[r] = 0.f; acc_z[r] = 0.f; acc_ni[r] = 0.f; acc_nh[r] = 0.f;
-    }
-
-    if (wave >= 4) {
-        // ---------------- loader waves ----------------
-        // wave lw issues instructions 8*lw .. 8*lw+7 of a chunk; instruction q
-        // fills stage rows 4q .. 4q+3 (rows 0-31: activations, 32-127: weights);
-        // lane -> (row 4q + lane/16, granule slot lane%16)
-        const int lw = wave - 4;
-        const char *xb = (const char *)a.xin, *hb = (const char *)a.hprev;
-        const char *wb = (const char *)a.wpack;
-        uint32_t off0[8], off1[8];  // lw == 0: x / h offsets; else weights in off0
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = 4 * (lw * 8 + i) + (lane >> 4);
-            const int g = (lane & 15) ^ (row & 15);   // source granule (swizzle)
-            if (lw == 0) {
-                // rows past the batch re-read the last row (never stored)
-                const int b = min(b0 + row, a.B - 1);
-                off0[i] = (uint32_t)(b * a.ldx + g * 4) * 4u;
-                off1[i] = (uint32_t)(b * a.Hp + g * 4) * 4u;
-            } else {
-                const int wr = row - CM, gate = wr >> 5, jj = wr & 31;
-                off0[i] = (uint32_t)((gate * a.Hn + j0 + jj) * a.Kp + g * 4) * 4u;
-                off1[i] = 0;
-            }
-        }
-        const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
-            (uint32_t)(size_t)(__attribute__((address_space(3))) void *)lds);
-        auto issue = [&](int cc) {
-            const int c = min(cc, last);   // the tail re-reads the last chunk
-            const uint32_t dst =
-                lds0 + ((cc & (GNSTAGE - 1)) * GSTAGE + lw * 8 * 256) * 4u;
-            if (lw == 0) {
-                if (c < a.nx_chunks)
-                    glds8(xb + c * (CK * 4), off0, dst);
-                else
-                    glds8(hb + (c - a.nx_chunks) * (CK * 4), off1, dst);
-            } else {
-                glds8(wb + c * (CK * 4), off0, dst);
-            }
-        };
-        issue(0); issue(1); issue(2); issue(3);
-        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // chunks 0, 1 landed
-        raw_barrier();                                      // barrier #0
-        raw_barrier();  // #0b: the consumers hold chunk 0's fragments
-        for (int k = 0; k < npad; ++k) {
-            // stage of chunk k is free: its fragments were read before the
-            // barrier that ended iteration k - 1
-            issue(k + 4);
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // chunk k+2 landed
-            raw_barrier();
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-        // ---------------- consumer waves ----------------
-        // this wave's 16-wide k slice; lane half lh supplies k = 8s + 4*lh + e,
-        // i.e. granule 4*wave + lh + 2s of its row, stored at slot ^ (row & 15)
-        int slot[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-            slot[s] = lrow * CK + (((4 * wave + lh + 2 * s) ^ (lrow & 15)) << 2);
-        f32x4 fa0[2], fr0[2], fz0[2], fn0[2];
-        f32x4 fa1[2], fr1[2], fz1[2], fn1[2];
-        auto read_frags = [&](int cc, f32x4 (&fa)[2], f32x4 (&fr)[2],
-                              f32x4 (&fz)[2], f32x4 (&fn)[2]) {
-            const float *As = lds + (cc & (GNSTAGE - 1)) * GSTAGE;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                fa[s] = *(const f32x4 *)(As + slot[s]);
-                fr[s] = *(const f32x4 *)(As + (CM + 0 * CN) * CK + slot[s]);
-                fz[s] = *(const f32x4 *)(As + (CM + 1 * CN) * CK + slot[s]);
-                fn[s] = *(const f32x4 *)(As + (CM + 2 * CN) * CK + slot[s]);
-            }
-        };
-        auto mfma_chunk = [&](int c, const f32x4 (&fa)[2], const f32x4 (&fr)[2],
-                              const f32x4 (&fz)[2], const f32x4 (&fn)[2]) {
-            if (c < a.nx_chunks) {
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            fa[s][e], fr[s][e], acc_r, 0, 0, 0);
-                        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            fa[s][e], fz[s][e], acc_z, 0, 0, 0);
-                        acc_ni = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            fa[s][e], fn[s][e], acc_ni, 0, 0, 0);
-                    }
-            } else {
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            fa[s][e], fr[s][e], acc_r, 0, 0, 0);
-                        acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            fa[s][e], fz[s][e], acc_z, 0, 0, 0);
-                        acc_nh = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                            fa[s][e], fn[s][e], acc_nh, 0, 0, 0);
-                    }
-            }
-        };
-        raw_barrier();  // barrier #0
-        read_frags(0, fa0, fr0, fz0, fn0);
-        raw_barrier();  // #0b: stage 0 may be refilled from here on
-        for (int c = 0; c < npad; c += 2) {
-            read_frags(c + 1, fa1, fr1, fz1, fn1);   // prefetch chunk c + 1
-            if (c < nchunks) mfma_chunk(c, fa0, fr0, fz0, fn0);
-            raw_barrier();
-            read_frags(c + 2, fa0, fr0, fz0, fn0);   // prefetch chunk c + 2
-            if (c + 1 < nchunks) mfma_chunk(c + 1, fa1, fr1, fz1, fn1);
-            raw_barrier();
-        }
-    }
-
+// Cross-wave reduction of the four K-slice partials through LDS, then the GRU
+// cell epilogue for the 32 x 32 tile (two outputs per thread).
+__device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
+                                              const f32x16 &acc_r,
+                                              const f32x16 &acc_z,
+                                              const f32x16 &acc_ni,
+                                              const f32x16 &acc_nh, int tid,
+                                              int wave, int lrow, int lh,
+                                              int j0, int b0) {
     // cross-wave reduction of the 4 partial tiles through LDS
     __syncthreads();
     float *red = lds;  // [wave][tile][32][32]
@@ -274,6 +148,115 @@ __global__ __launch_bounds__(512) void gru_cell_fwd_kernel(CellFwdArgs a) {
                 hn * pcm_dropout_scale(a.seed, a.next_layer, a.t, b, j,
                                        a.drop_p, a.inv_keep);
     }
+}
+
+// Two 32 KiB stages, two raw barriers per chunk (A: chunk landed, B: fragments
+// read, stage free), one fragment set, accumulators updated in place in two
+// straight loops (input part, hidden part).  Deeper pipelines (3-4 stages, one
+// barrier per chunk, fragment double buffering) were measured and are slower:
+// the MFMA loop already sits at its issue bound, and at 64 KiB LDS / 86 VGPRs
+// two blocks fit a CU, so with more blocks than CUs (large batches) one block's
+// prologue and epilogue run under the other's main loop.
+constexpr int CNSTAGE = 2;
+static_assert(CNSTAGE * GSTAGE >= 4 * 4 * 1024, "reduction buffer must fit");
+
+__global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[CNSTAGE * GSTAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j0 = blockIdx.x * CN;
+    const int b0 = blockIdx.y * CM;
+    const int nchunks = a.nx_chunks + a.nh_chunks;
+    const int last = nchunks - 1;
+    const int lrow = lane & 31, lh = lane >> 5;
+
+    f32x16 acc_r, acc_z, acc_ni, acc_nh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc_r[r] = 0.f; acc_z[r] = 0.f; acc_ni[r] = 0.f; acc_nh[r] = 0.f;
+    }
+
+    if (wave >= 4) {
+        // loaders: same lane -> (row, swizzled granule) map as above
+        const int lw = wave - 4;
+        const char *xb = (const char *)a.xin, *hb = (const char *)a.hprev;
+        const char *wb = (const char *)a.wpack;
+        uint32_t off0[8], off1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * (lw * 8 + i) + (lane >> 4);
+            const int g = (lane & 15) ^ (row & 15);
+            if (lw == 0) {
+                const int b = min(b0 + row, a.B - 1);
+                off0[i] = (uint32_t)(b * a.ldx + g * 4) * 4u;
+                off1[i] = (uint32_t)(b * a.Hp + g * 4) * 4u;
+            } else {
+                const int wr = row - CM, gate = wr >> 5, jj = wr & 31;
+                off0[i] = (uint32_t)((gate * a.Hn + j0 + jj) * a.Kp + g * 4) * 4u;
+                off1[i] = 0;
+            }
+        }
+        const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(size_t)(__attribute__((address_space(3))) void *)lds);
+        auto issue = [&](int cc) {
+            const int c = min(cc, last);
+            const uint32_t dst =
+                lds0 + ((cc % CNSTAGE) * GSTAGE + lw * 8 * 256) * 4u;
+            if (lw == 0) {
+                if (c < a.nx_chunks)
+                    glds8(xb + c * (CK * 4), off0, dst);
+                else
+                    glds8(hb + (c - a.nx_chunks) * (CK * 4), off1, dst);
+            } else {
+                glds8(wb + c * (CK * 4), off0, dst);
+            }
+        };
+        issue(0); issue(1);
+        for (int k = 0; k < nchunks; ++k) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // chunk k landed
+            raw_barrier();   // A_k: the consumers may read chunk k
+            raw_barrier();   // B_k: they hold its fragments, the stage is free
+            issue(k + 2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        int slot[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            slot[s] = lrow * CK + (((4 * wave + lh + 2 * s) ^ (lrow & 15)) << 2);
+        // two straight loops (input part, hidden part) so that every accumulator
+        // is updated in place -- a branch inside one loop makes hipcc ping-pong
+        // the accumulators between two register sets
+        auto chunk = [&](int c, f32x16 &acc_n) {
+            f32x4 fa[2], fr[2], fz[2], fn[2];
+            raw_barrier();   // A_c
+            const float *As = lds + (c % CNSTAGE) * GSTAGE;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                fa[s] = *(const f32x4 *)(As + slot[s]);
+                fr[s] = *(const f32x4 *)(As + (CM + 0 * CN) * CK + slot[s]);
+                fz[s] = *(const f32x4 *)(As + (CM + 1 * CN) * CK + slot[s]);
+                fn[s] = *(const f32x4 *)(As + (CM + 2 * CN) * CK + slot[s]);
+            }
+            raw_barrier();   // B_c (waits for the fragment reads first)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[s][e], fr[s][e], acc_r, 0, 0, 0);
+                    acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[s][e], fz[s][e], acc_z, 0, 0, 0);
+                    acc_n = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[s][e], fn[s][e], acc_n, 0, 0, 0);
+                }
+        };
+        for (int c = 0; c < a.nx_chunks; ++c) chunk(c, acc_ni);
+        for (int c = a.nx_chunks; c < nchunks; ++c) chunk(c, acc_nh);
+    }
+    cell_fwd_tail(a, lds, acc_r, acc_z, acc_ni, acc_nh, tid, wave, lrow, lh, j0,
+                  b0);
 }
 
 // ------------------------------------------------------------------------------
