@@ -7,6 +7,8 @@
 //              weight-gradient GEMMs) and the direct dL/dh_{t-1} = dL/dh_t * z
 //   stack_bwd  adjoint of the push/pop/no-op update, control softmax and push
 //              tanh; adds (dc.Wc + du.Ws) into dL/dh_{t-1} of the top layer
+#include <stdlib.h>
+
 #include "stackgru.h"
 
 namespace {
@@ -231,11 +233,9 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
 // ------------------------------------------------------------------------------
 constexpr int BCK = 64;         // K per chunk
 constexpr int BCM = 32;         // batch rows per block
-constexpr int BCN = 64;         // output columns per block (2 MFMA tiles)
-constexpr int BSTAGE = (BCM + BCN) * BCK;   // floats per LDS stage (24 KiB)
-constexpr int BNSTAGE = 2;
-constexpr int BCELL_LDS = BNSTAGE * BSTAGE; // 48 KiB
-static_assert(BCELL_LDS >= 4 * 2 * 1024, "reduction buffer must fit");
+// output columns per block: BCN = 64 (2 MFMA tiles, 24 KiB stages) or 32 (one
+// tile, 16 KiB stages) -- the narrow variant doubles the block count when the
+// wide one leaves CUs idle (layer 0: 9 x 16 wide tiles on 256 CUs)
 
 // Wave-specialised like the forward cell: waves 4-7 stream the operand chunks
 // into LDS with LDS-DMA loads (global_load_lds_dwordx4; unpadded 256-byte rows,
@@ -277,12 +277,44 @@ __device__ __forceinline__ void glds6(const char *const (&base)[6],
         : "memory", "scc");
 }
 
+__device__ __forceinline__ void glds4(const char *const (&base)[4],
+                                      const uint32_t (&off)[4],
+                                      uint32_t lds_byte) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %6, %2\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %7, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %8, %4\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %9, %5\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_byte), "s"(base[0]), "s"(base[1]), "s"(base[2]), "s"(base[3]),
+          "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3])
+        : "memory", "scc");
+}
+
 __device__ __forceinline__ void raw_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 }
 
+template <int BCN, int BNSTAGE>
 __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
+    constexpr int BSTAGE = (BCM + BCN) * BCK;    // floats per LDS stage
+    constexpr int BCELL_LDS = BNSTAGE * BSTAGE;  // 48 / 32 KiB
+    constexpr int NTL = BCN / 32;                // MFMA tiles per block
+    constexpr int NQ = BCN / 16;                 // epilogue outputs per thread
+    constexpr int NI = (BCM + BCN) / 16;         // DMA instructions per loader wave
+    static_assert(BCELL_LDS >= 4 * NTL * 1024, "reduction buffer must fit");
     __shared__ __attribute__((aligned(16))) float lds[BCELL_LDS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -314,7 +346,7 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
     // gates) and with in-order vmcnt they are the oldest loads of either role,
     // so their latency is paid once under the first chunk's DMA instead of at
     // the end of the kernel.
-    float pre_d[4], pre_r[4], pre_z[4], pre_n[4], pre_g[4], pre_h[4];
+    float pre_d[NQ], pre_r[NQ], pre_z[NQ], pre_n[NQ], pre_g[NQ], pre_h[NQ];
     int pre_len[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -322,7 +354,7 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
         pre_len[q] = a.lengths ? a.lengths[b] : 0x7fffffff;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int e = tid + 512 * q;
         const int tl = e >> 10, ee = e & 1023;
         const int b = min(b0 + (ee >> 5), a.B - 1);
@@ -350,11 +382,11 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
         // lane -> (row 4q + lane/16, granule slot lane%16)
         const int lw = wave - 4;
         const char *gb = (const char *)a.dgates, *wb = (const char *)a.wpackT;
-        uint32_t off[6];
-        bool is_a[6];
+        uint32_t off[NI];
+        bool is_a[NI];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int q = lw * 6 + i;
+        for (int i = 0; i < NI; ++i) {
+            const int q = lw * NI + i;
             const int row = 4 * q + (lane >> 4);
             const int g = (lane & 15) ^ (row & 15);   // source granule (swizzle)
             is_a[i] = q < BCM / 4;
@@ -372,19 +404,23 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
             const int kb = min(cc, last) * BCK;  // the tail re-reads the last chunk
             // dgates columns: [0,2H) shared; third segment dni at 2H, dnh at 3H
             const int acol = (kb >= 2 * H && hidden_side) ? kb + H : kb;
-            const char *base[6];
+            const char *base[NI];
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < NI; ++i)
                 base[i] = is_a[i] ? gb + acol * 4 : wb + kb * 4;
-            glds6(base, off,
-                  lds0 + ((cc & (BNSTAGE - 1)) * BSTAGE + lw * 6 * 256) * 4u);
+            const uint32_t dst =
+                lds0 + ((cc % BNSTAGE) * BSTAGE + lw * NI * 256) * 4u;
+            if constexpr (NI == 6) glds6(base, off, dst);
+            else glds4(base, off, dst);
         };
-        issue(0); issue(1);
+#pragma unroll
+        for (int c = 0; c < BNSTAGE; ++c) issue(c);
         for (int k = 0; k < nchunks; ++k) {
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // chunk k landed
+            // chunk k landed (the newest BNSTAGE - 1 chunks may be in flight)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (BNSTAGE - 1)) : "memory");
             raw_barrier();   // A_k: the consumers may read chunk k
             raw_barrier();   // B_k: they hold its fragments, the stage is free
-            issue(k + 2);
+            issue(k + BNSTAGE);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -401,12 +437,13 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
         for (int c = 0; c < nchunks; ++c) {
             f32x4 fa[2], f0[2], f1[2];
             raw_barrier();   // A_c
-            const float *As = lds + (c & (BNSTAGE - 1)) * BSTAGE;
+            const float *As = lds + (c % BNSTAGE) * BSTAGE;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 fa[s] = *(const f32x4 *)(As + slot[s]);
                 f0[s] = *(const f32x4 *)(As + BCM * BCK + slot[s]);
-                f1[s] = *(const f32x4 *)(As + (BCM + 32) * BCK + slot[s]);
+                if constexpr (NTL == 2)
+                    f1[s] = *(const f32x4 *)(As + (BCM + 32) * BCK + slot[s]);
             }
             raw_barrier();   // B_c (waits for the fragment reads first)
 #pragma unroll
@@ -415,8 +452,9 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(
                         fa[s][e], f0[s][e], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                        fa[s][e], f1[s][e], acc1, 0, 0, 0);
+                    if constexpr (NTL == 2)
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                            fa[s][e], f1[s][e], acc1, 0, 0, 0);
                 }
         }
     }
@@ -427,21 +465,21 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            float *base = red + (wave * 2) * 1024 + row * 32 + lrow;
+            float *base = red + (wave * NTL) * 1024 + row * 32 + lrow;
             base[0] = acc0[r];
-            base[1024] = acc1[r];
+            if constexpr (NTL == 2) base[1024] = acc1[r];
         }
     }
     __syncthreads();
 
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = tid + 512 * q;       // 0..2047
+    for (int q = 0; q < NQ; ++q) {
+        const int e = tid + 512 * q;       // 0..32*BCN-1
         const int tl = e >> 10, ee = e & 1023;
         const int row = ee >> 5, col = ee & 31;
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) v += red[(w * 2 + tl) * 1024 + ee];
+        for (int w = 0; w < 4; ++w) v += red[(w * NTL + tl) * 1024 + ee];
         const int b = b0 + row, n = n0 + tl * 32 + col;
         if (b >= a.B) continue;
         if (hidden_side) {
@@ -531,12 +569,34 @@ int pcm_launch_gate_bwd(const GateBwdArgs &a, hipStream_t stream) {
 }
 
 int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream) {
-    const int nct = a.NT / BCN, nbt = (a.B + BCM - 1) / BCM;
+    // Narrow (32-column) tiles with a third LDS stage when the wide ones would
+    // give each CU at most one block: the per-block MFMA time halves and two
+    // blocks share a CU (measured 29.4 -> 28.7 ms per training step at batch
+    // 512).  PCM_BWD_TILE=32|64 forces a width.
+    static const int force = [] {
+        const char *e = getenv("PCM_BWD_TILE");
+        return e ? atoi(e) : 0;
+    }();
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess)
+            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount,
+                                        dev);
+        return n;
+    }();
+    const int nbt = (a.B + BCM - 1) / BCM;
+    const bool narrow = force ? force == 32 : (a.NT / 64) * nbt <= cus;
+    const int nct = a.NT / (narrow ? 32 : 64);
     CellBwdArgs b = a;
     b.reg_cols = (nct + 3) / 4;
     b.reg_rows = (nbt + 1) / 2;
     dim3 grid(8 * b.reg_cols * b.reg_rows);
-    hipLaunchKernelGGL(gru_cell_bwd_kernel, grid, dim3(512), 0, stream, b);
+    if (narrow)
+        hipLaunchKernelGGL((gru_cell_bwd_kernel<32, 3>), grid, dim3(512), 0,
+                           stream, b);
+    else
+        hipLaunchKernelGGL((gru_cell_bwd_kernel<64, 2>), grid, dim3(512), 0,
+                           stream, b);
     return 0;
 }
 
