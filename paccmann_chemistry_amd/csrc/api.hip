@@ -12,6 +12,12 @@ int pcm_launch_choose(const float *logits, int B, int V, int search,
                       float temperature, uint64_t seed, int step,
                       int64_t *next_tok, int64_t *tokens_out,
                       long long out_stride, int out_col, hipStream_t stream);
+int pcm_launch_logits_choose(const float *h, long long ldh, const float *w,
+                             const float *bias, int B, int V, int H, int search,
+                             float temperature, uint64_t seed, int step,
+                             int64_t *next_tok, int64_t *tokens_out,
+                             long long out_stride, int out_col,
+                             float *logits_out, hipStream_t stream);
 int pcm_launch_broadcast_token(const int64_t *src, int B, int64_t *next_tok,
                                int64_t *tokens_out, long long out_stride,
                                int out_col, hipStream_t stream);
@@ -1132,6 +1138,18 @@ int pcm_stackgru_generate(const pcm_dims *dims,
         slot ^= 1;
         if (!priming) {
             const int gi = s - (prime_len - 1);
+            // output layer + search step, fused when the shape allows
+            static const bool fuse = [] {
+                const char *e = getenv("PCM_FUSED_CHOOSE");
+                return !e || atoi(e) != 0;
+            }();
+            if (fuse &&
+                pcm_launch_logits_choose(
+                    ws + g.off_h[slot][L - 1], Hp, out_w, out_b, B, V, H, search,
+                    temperature, seed, gi, cur_tok, tokens_out, out_stride,
+                    prime_len + gi,
+                    logits_out ? logits_out + (size_t)gi * B * V : nullptr, st))
+                continue;
             float *logits = logits_out ? logits_out + (size_t)gi * B * V
                                        : ws + g.off_logits;
             rc = pcm_linear_forward(ws + g.off_h[slot][L - 1], Hp, out_w, out_b,

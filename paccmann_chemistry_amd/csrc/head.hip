@@ -203,6 +203,127 @@ __global__ __launch_bounds__(256) void choose_token_kernel(
     tokens_out[(long long)b * out_stride + out_col] = pick;
 }
 
+// Output layer + token choice of one decode step in one launch (vae.py:455-464:
+// output_layer, search.step): a block takes 32 batch rows; its 4 waves share
+// the (column tile, K part) items of logits = h . Wout^T on fp32 MFMA with
+// operands read straight from L2 (h was just written, Wout is 120 KB), the
+// partial tiles meet in LDS, and one thread per row scans its V logits with
+// the same arithmetic as choose_token_kernel.  Replaces a 35 us generic GEMM
+// + a 21 us one-thread-per-row scan (batch 4096) on the decode critical path.
+struct LogitsChooseArgs {
+    const float *h;        // [B, ldh] top-layer hidden
+    const float *w;        // [V, H]
+    const float *bias;     // [V] or null
+    float *logits_out;     // [B, V] or null
+    int64_t *next_tok;     // [B]
+    int64_t *tokens_out;   // [B, out_stride]
+    long long ldh, out_stride;
+    int B, V, H, NT, ksplit, search, step, out_col;
+    float inv_temp;
+    uint64_t seed;
+};
+constexpr int LC_MAX_ITEMS = 8;
+constexpr int LC_LD = 33;   // padded row of a 32 x 32 tile in LDS
+
+__global__ __launch_bounds__(256) void logits_choose_kernel(LogitsChooseArgs a) {
+    __shared__ float part[LC_MAX_ITEMS][32][LC_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, lh = lane >> 5;
+    const int b0 = blockIdx.x * 32;
+    const int items = a.NT * a.ksplit, klen = a.H / a.ksplit;
+    const float *hrow = a.h + (long long)min(b0 + lrow, a.B - 1) * a.ldh + 4 * lh;
+    for (int item = wave; item < items; item += 4) {
+        const int tile = item % a.NT, kp = item / a.NT;
+        const float *wrow =
+            a.w + (long long)min(tile * 32 + lrow, a.V - 1) * a.H + 4 * lh;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int kend = (kp + 1) * klen;
+        int k = kp * klen;
+        // 8 fragment pairs (64 of K) in flight per round, then the remainder
+        for (; k + 64 <= kend; k += 64) {
+            f32x4 fa[8], fb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                fa[i] = *(const f32x4 *)(hrow + k + 8 * i);
+                fb[i] = *(const f32x4 *)(wrow + k + 8 * i);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[i][e],
+                                                               acc, 0, 0, 0);
+        }
+        for (; k < kend; k += 8) {
+            const f32x4 fa = *(const f32x4 *)(hrow + k);
+            const f32x4 fb = *(const f32x4 *)(wrow + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0,
+                                                           0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            part[item][(r & 3) + 8 * (r >> 2) + 4 * lh][lrow] = acc[r];
+    }
+    __syncthreads();
+    // final logits (K parts summed in order, bias last as the GEMM does) land
+    // in the first K part's tiles
+    for (int idx = tid; idx < 32 * a.V; idx += 256) {
+        const int r = idx / a.V, v = idx - r * a.V;
+        const int tile = v >> 5, c = v & 31;
+        float x = part[tile][r][c];
+        for (int kp = 1; kp < a.ksplit; ++kp) x += part[kp * a.NT + tile][r][c];
+        if (a.bias) x += a.bias[v];
+        part[tile][r][c] = x;
+        if (a.logits_out && b0 + r < a.B)
+            a.logits_out[(long long)(b0 + r) * a.V + v] = x;
+    }
+    __syncthreads();
+    __shared__ float rowmax[32];
+    const int b = b0 + tid;
+    auto lg = [&](int v) -> float & { return part[v >> 5][tid][v & 31]; };
+    int pick = 0;
+    if (tid < 32) {
+        float m = -INFINITY;
+        for (int v = 0; v < a.V; ++v) {
+            const float xv = lg(v);
+            if (xv > m) { m = xv; pick = v; }
+        }
+        rowmax[tid] = m;
+    }
+    if (a.search == PCM_SEARCH_SAMPLING) {
+        // softmax(logits / T), inverse-CDF draw: the exponentials are taken by
+        // all threads, the sums stay one thread's, in vocabulary order
+        __syncthreads();
+        for (int idx = tid; idx < 32 * a.V; idx += 256) {
+            const int r = idx / a.V, v = idx - r * a.V;
+            float &x = part[v >> 5][r][v & 31];
+            x = expf((x - rowmax[r]) * a.inv_temp);
+        }
+        __syncthreads();
+        if (tid < 32) {
+            float s = 0.f;
+            for (int v = 0; v < a.V; ++v) s += lg(v);
+            const float u =
+                pcm_uniform(a.seed, ((uint64_t)(uint32_t)a.step << 32) |
+                                        (uint32_t)b) * s;
+            float c = 0.f;
+            pick = a.V - 1;
+            for (int v = 0; v < a.V; ++v) {
+                c += lg(v);
+                if (c > u) { pick = v; break; }
+            }
+        }
+    }
+    if (tid >= 32 || b >= a.B) return;
+    a.next_tok[b] = pick;
+    a.tokens_out[(long long)b * a.out_stride + a.out_col] = pick;
+}
+
 __global__ __launch_bounds__(256) void broadcast_token_kernel(
     const int64_t *src, int B, int64_t *next_tok, int64_t *tokens_out,
     long long out_stride, int out_col) {
@@ -221,6 +342,28 @@ int pcm_launch_choose(const float *logits, int B, int V, int search,
                        stream, logits, B, V, search, 1.0f / temperature, seed,
                        step, next_tok, tokens_out, out_stride, out_col);
     return 0;
+}
+
+// 1 = launched; 0 = shape not covered (caller falls back to GEMM + choose)
+int pcm_launch_logits_choose(const float *h, long long ldh, const float *w,
+                             const float *bias, int B, int V, int H, int search,
+                             float temperature, uint64_t seed, int step,
+                             int64_t *next_tok, int64_t *tokens_out,
+                             long long out_stride, int out_col,
+                             float *logits_out, hipStream_t stream) {
+    const int NT = (V + 31) / 32;
+    if (NT > LC_MAX_ITEMS || (H % 32) != 0 || (ldh % 4) != 0) return 0;
+    LogitsChooseArgs a;
+    a.h = h; a.w = w; a.bias = bias; a.logits_out = logits_out;
+    a.next_tok = next_tok; a.tokens_out = tokens_out;
+    a.ldh = ldh; a.out_stride = out_stride;
+    a.B = B; a.V = V; a.H = H; a.NT = NT;
+    a.ksplit = NT >= 4 ? 1 : 4 / NT;   // H % 32 == 0: every part is whole 8s
+    a.search = search; a.step = step; a.out_col = out_col;
+    a.inv_temp = 1.0f / temperature; a.seed = seed;
+    hipLaunchKernelGGL(logits_choose_kernel, dim3((B + 31) / 32), dim3(256), 0,
+                       stream, a);
+    return 1;
 }
 
 int pcm_launch_broadcast_token(const int64_t *src, int B, int64_t *next_tok,

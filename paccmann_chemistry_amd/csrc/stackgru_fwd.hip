@@ -262,15 +262,22 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
 // ------------------------------------------------------------------------------
 // stack controls + fused stack update
 // ------------------------------------------------------------------------------
+constexpr int SROWS = 2;
 // One block of 512 threads per SROWS batch rows.  The rows' previous stacks are
 // staged into LDS while the 3+W control / push dot products run (weights
 // stream from L2, 8 waves x 7 outputs, lanes along K), so the update itself
 // reads HBM once and writes once (20 KB / row, the algorithmic minimum).
-constexpr int SROWS = 2;
 constexpr int STHREADS = 512;
 constexpr int SOUT = 7;  // outputs per wave (8 waves x 7 = 56 >= 3 + W)
 
-__global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
+// LEAN: no register prefetch of the weights / previous stack rows.  The
+// prefetching variant needs 200 VGPRs (one block per CU): best when the grid is
+// a single round of blocks (batch 512 = 256 blocks, the step is latency-bound);
+// with more rows than that the lean one keeps several blocks per CU in flight.
+// (80 VGPRs, three blocks per CU: 72.9 -> 39.1 us per step at batch 4096; four
+// rows per block or a deeper unroll of the dot loop measured no better).
+template <bool LEAN>
+__global__ __launch_bounds__(STHREADS, LEAN ? 4 : 2) void stack_step_fwd_kernel(
     StackFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int H = a.H, W = a.W, D = a.D, DW = D * W, NO = 3 + W;
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
     // control / push weights of this wave's outputs go to registers FIRST so
     // their L2 round trip overlaps the staging loads below (H <= 512 path)
     constexpr int KS = 8;
-    const bool wregs = H <= 64 * KS && NO <= 8 * SOUT;
+    const bool wregs = !LEAN && H <= 64 * KS && NO <= 8 * SOUT;
     float wr[SOUT][KS];
     if (wregs) {
 #pragma unroll
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
     constexpr int SQ = 4;  // float4 per thread held in flight
     const bool vec = (DW & 3) == 0;
     const int nq = DW >> 2;
-    const bool sregs = vec && SROWS * nq <= SQ * STHREADS;
+    const bool sregs = !LEAN && vec && SROWS * nq <= SQ * STHREADS;
     f32x4 sq[SQ];
     if (sregs) {
 #pragma unroll
@@ -462,7 +469,7 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
         const int b = b0 + r;
         if (b < a.B) a.av[(long long)b * a.AVW + o] = o < NO ? cu[idx] : 0.f;
     }
-    auto updated = [&](int r, int e, bool frozen, float *top_w) -> float {
+    auto updated = [&](int r, int e, bool frozen) -> float {
         const int d = pcm_fdiv(e, inv_W), w = e - d * W;
         const float *Sp = Srow + r * DWp;
         const float sv = Sp[e];
@@ -475,7 +482,6 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
             nv = __fadd_rn(__fadd_rn(__fmul_rn(c[2], sv), __fmul_rn(c[0], up)),
                            __fmul_rn(c[1], dn));
         }
-        if (d == 0) *top_w = nv;
         return nv;
     };
     if (vec) {
@@ -489,8 +495,8 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int e = q * 4 + i;
-                float dummy;
-                nv[i] = updated(r, e, frozen, e < W ? xt + e : &dummy);
+                nv[i] = updated(r, e, frozen);
+                if (e < W) xt[e] = nv[i];   // row 0 = the new stack top
             }
             *(f32x4 *)(a.S_new + (long long)b * DW + q * 4) = nv;
         }
@@ -500,9 +506,9 @@ __global__ __launch_bounds__(STHREADS) void stack_step_fwd_kernel(
             const int b = b0 + r;
             if (b >= a.B) continue;
             const bool frozen = a.lengths && a.t >= a.lengths[b];
-            float dummy;
-            a.S_new[(long long)b * DW + e] = updated(
-                r, e, frozen, e < W ? a.xtop + (long long)b * a.Wp + e : &dummy);
+            const float nv = updated(r, e, frozen);
+            a.S_new[(long long)b * DW + e] = nv;
+            if (e < W) a.xtop[(long long)b * a.Wp + e] = nv;
         }
     }
     const int padw = a.Wp - W;
@@ -612,13 +618,29 @@ int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
 
 int pcm_launch_stack_fwd(const StackFwdArgs &a, hipStream_t stream) {
     const int DWp = (a.D * a.W + 3) & ~3;
-    const size_t lds = (size_t)SROWS * (DWp + a.H + a.AVW) * sizeof(float);
-    PCM_REQUIRE(lds <= 64 * 1024, PCM_EINVAL,
+    const size_t row_bytes = (size_t)(DWp + a.H + a.AVW) * sizeof(float);
+    PCM_REQUIRE(2 * row_bytes <= 64 * 1024, PCM_EINVAL,
                 "stack step: stack %dx%d + hidden %d exceed the 64 KiB LDS "
                 "row cache", a.D, a.W, a.H);
-    dim3 grid((a.B + SROWS - 1) / SROWS);
-    hipLaunchKernelGGL(stack_step_fwd_kernel, grid, dim3(STHREADS), lds, stream,
-                       a);
+    static const int force = [] {
+        const char *e = getenv("PCM_STACK_LEAN");  // 0 / 1: force a variant
+        return e ? atoi(e) : -1;
+    }();
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess)
+            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount,
+                                        dev);
+        return n;
+    }();
+    const dim3 grid((a.B + SROWS - 1) / SROWS);
+    const bool lean = force >= 0 ? force == 1 : (int)grid.x > cus;
+    if (lean)
+        hipLaunchKernelGGL(stack_step_fwd_kernel<true>, grid, dim3(STHREADS),
+                           SROWS * row_bytes, stream, a);
+    else
+        hipLaunchKernelGGL(stack_step_fwd_kernel<false>, grid, dim3(STHREADS),
+                           SROWS * row_bytes, stream, a);
     return 0;
 }
 

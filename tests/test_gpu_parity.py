@@ -559,6 +559,51 @@ def test_flat_adam_matches_torch_adam():
     assert torch.isfinite(loss).item()
 
 
+DECODE_SWEEP = {
+    # vocab tiles of the fused output-layer + search kernel: one (V <= 32),
+    # two with a K split (the tuned V = 60 shape), four / five (no K split),
+    # and shapes it does not take (H % 32 != 0, V > 256: GEMM + scan fallback)
+    'v20': dict(vocab_size=20, embedding_size=20, rnn_cell_size=64),
+    'v60_h512': dict(vocab_size=60, embedding_size=60, rnn_cell_size=512,
+                     stack_width=50, stack_depth=50, latent_dim=256),
+    'v100': dict(vocab_size=100, embedding_size=100, rnn_cell_size=96),
+    'v150_l1': dict(vocab_size=150, embedding_size=150, rnn_cell_size=128,
+                    n_layers=1),
+    'v30_h48': dict(vocab_size=30, embedding_size=30, rnn_cell_size=48),
+    'v300': dict(vocab_size=300, embedding_size=300, rnn_cell_size=64),
+}
+
+
+@pytest.mark.parametrize('name', sorted(DECODE_SWEEP))
+def test_greedy_decode_matches_oracle(name):
+    """generate_from_latent, greedy (vae.py:422-468, search.py:76-87): tokens
+    bit-exact and per-step logits within tolerance against the oracle, at a
+    batch that is not a multiple of the 32-row tile."""
+    from paccmann_chemistry_amd import GreedySearch
+    p = {
+        'latent_dim': 16, 'rnn_cell_size': 32, 'embedding_size': 20,
+        'vocab_size': 20, 'stack_width': 5, 'stack_depth': 7, 'n_layers': 2,
+        'dropout': 0.0, 'batch_size': 70, 'batch_mode': 'padded',
+        'embedding': 'one_hot', 'use_stack': True, 'bidirectional': False
+    }
+    p.update(DECODE_SWEEP[name])
+    sd = W.make_state_dict(p, 77)
+    vae = _build_vae(p, sd, train=False)
+    z = torch.from_numpy(np.random.default_rng(78).standard_normal(
+        (p['batch_size'], p['latent_dim'])).astype(np.float32))
+    prime = torch.tensor([2, 5])
+    tokens, logits = vae.decoder.generate_from_latent(
+        z.unsqueeze(0).to(_dev()), prime.to(_dev()), torch.tensor([3]),
+        search=GreedySearch(), generate_len=12, return_logits=True
+    )
+    dec = O.sub_params(sd, 'decoder')
+    with torch.no_grad():
+        r_tokens, r_logits = O.generate_from_latent(
+            dec, z, prime, 12, p['stack_depth'], p['use_stack'])
+    assert _rel_to_max(logits, r_logits.numpy()) < LOGIT_TOL
+    assert torch.equal(tokens.cpu(), r_tokens)
+
+
 def test_sampling_search_distribution():
     """SamplingSearch.step (search.py:124-141): device draws follow
     softmax(logits / T); checked through generation statistics."""
