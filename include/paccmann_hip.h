@@ -124,6 +124,13 @@ size_t pcm_stackgru_scratch_bytes(const pcm_dims *dims, int32_t steps);
  *            updated while t < lengths[b] and frozen afterwards; for
  *            t >= lengths[b] its out[t][b][:] repeats the frozen top-layer
  *            hidden state and carries no gradient.
+ *   active_rows  HOST int32[T] or NULL (needs lengths): the rows still running
+ *            at each step when the batch is sorted by decreasing length, i.e.
+ *            PackedSequence.batch_sizes (utils/utils.py:215-243, where the
+ *            reference slices hidden/stack to the active prefix every step).
+ *            Steps then launch over rows [0, active_rows[t]) only; must be
+ *            non-increasing and agree with lengths.  out[t][b][:] is ZERO for
+ *            t >= lengths[b] in this mode.
  *   h0       fp32[L,B,H] initial hidden, element (l,b,j) at
  *            h0[l*h0_layer_stride + b*H + j] (stride 0 broadcasts one [B,H]
  *            to every layer, vae.py:564-565); NULL = zeros (stack_rnn.py:122)
@@ -139,16 +146,17 @@ size_t pcm_stackgru_scratch_bytes(const pcm_dims *dims, int32_t steps);
 int pcm_stackgru_forward(const pcm_dims *dims,
                          const pcm_stackgru_params *weights,
                          const int64_t *tokens, int32_t steps,
-                         const int32_t *lengths, const float *h0,
-                         int64_t h0_layer_stride, const float *stack0,
-                         float dropout_p, uint64_t seed, int32_t training,
-                         void *saved, size_t saved_bytes, float *h_final,
-                         float *stack_final, int32_t *status, void *stream);
+                         const int32_t *lengths, const int32_t *active_rows,
+                         const float *h0, int64_t h0_layer_stride,
+                         const float *stack0, float dropout_p, uint64_t seed,
+                         int32_t training, void *saved, size_t saved_bytes,
+                         float *h_final, float *stack_final, int32_t *status,
+                         void *stream);
 
 /*
  * Reverse pass of pcm_stackgru_forward (what autograd replays for
  * training.py:153).  `saved` is the workspace of a training-mode forward with
- * the same dims/steps/tokens/lengths/dropout_p/seed; it is consumed (the gate
+ * the same dims/steps/tokens/lengths/active_rows/dropout_p/seed; it is consumed (the gate
  * slots are overwritten by gate gradients).
  *
  *   d_out        fp32[T,B,H] gradient of every step's top-layer output,
@@ -162,8 +170,9 @@ int pcm_stackgru_forward(const pcm_dims *dims,
 int pcm_stackgru_backward(const pcm_dims *dims,
                           const pcm_stackgru_params *weights,
                           const int64_t *tokens, int32_t steps,
-                          const int32_t *lengths, float dropout_p,
-                          uint64_t seed, void *saved, size_t saved_bytes,
+                          const int32_t *lengths, const int32_t *active_rows,
+                          float dropout_p, uint64_t seed, void *saved,
+                          size_t saved_bytes,
                           const float *d_out, int64_t d_out_row_stride,
                           const float *d_h_final, const float *d_stack_final,
                           float *d_h0, float *d_stack0,

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpaccmann_hip.so')
 PCM_MAX_LAYERS = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 SEARCH_GREEDY = 0
 SEARCH_SAMPLING = 1
@@ -66,14 +66,14 @@ PROTOTYPES = {
     'pcm_stackgru_scratch_bytes': (_SZ, [_DIMS_P, _I32]),
     'pcm_stackgru_forward': (
         ctypes.c_int, [
-            _DIMS_P, _PARAMS_P, _VP, _I32, _VP, _VP, _I64, _VP, _F32, _U64,
-            _I32, _VP, _SZ, _VP, _VP, _VP, _VP
+            _DIMS_P, _PARAMS_P, _VP, _I32, _VP, _VP, _VP, _I64, _VP, _F32,
+            _U64, _I32, _VP, _SZ, _VP, _VP, _VP, _VP
         ]
     ),
     'pcm_stackgru_backward': (
         ctypes.c_int, [
-            _DIMS_P, _PARAMS_P, _VP, _I32, _VP, _F32, _U64, _VP, _SZ, _VP,
-            _I64, _VP, _VP, _VP, _VP, _PARAMS_P, _I32, _VP, _SZ, _VP
+            _DIMS_P, _PARAMS_P, _VP, _I32, _VP, _VP, _F32, _U64, _VP, _SZ,
+            _VP, _I64, _VP, _VP, _VP, _VP, _PARAMS_P, _I32, _VP, _SZ, _VP
         ]
     ),
     'pcm_linear_forward': (

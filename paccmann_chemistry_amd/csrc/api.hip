@@ -232,7 +232,12 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
                         const float *sv_tokg, float *const *wpack,
                         float *const *bpack, const StepBufs &sb,
                         const int32_t *lengths, int t, float drop_p,
-                        uint64_t seed, int32_t *status, hipStream_t st) {
+                        uint64_t seed, int32_t *status, hipStream_t st,
+                        int rows = -1) {
+    // rows: the length-sorted prefix of the batch still running at this step
+    // (packed mode with a shrinking active batch); -1 = all of it
+    const int Bt = rows < 0 ? lay.B : rows;
+    if (Bt == 0) return PCM_OK;
     if (lay.use_stack) {
         StackFwdArgs s;
         s.htop = sb.h_prev[lay.L - 1];
@@ -240,7 +245,7 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         s.ctrl_w = w->ctrl_w; s.ctrl_b = w->ctrl_b;
         s.push_w = w->push_w; s.push_b = w->push_b;
         s.av = sb.av; s.xtop = sb.xtop; s.lengths = lengths;
-        s.B = lay.B; s.H = lay.H; s.Hp = lay.Hp; s.D = lay.D; s.W = lay.W;
+        s.B = Bt; s.H = lay.H; s.Hp = lay.Hp; s.D = lay.D; s.W = lay.W;
         s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
         pcm_probe_begin(PCM_K_STACK_FWD, st);
         int rc = pcm_launch_stack_fwd(s, st);
@@ -261,7 +266,7 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         c.ldx = l == 0 ? lay.Wp : lay.Hp;
         c.nx_chunks = lay.Kxp[l] / 64; c.nh_chunks = lay.Hp / 64;
         c.Kp = lay.Kp[l];
-        c.B = lay.B; c.H = lay.H; c.Hn = lay.Hn; c.Hp = lay.Hp; c.V = lay.V;
+        c.B = Bt; c.H = lay.H; c.Hn = lay.Hn; c.Hp = lay.Hp; c.V = lay.V;
         c.t = t; c.next_layer = l + 1;
         c.drop_p = drop_p; c.inv_keep = drop_p < 1.f ? 1.f / (1.f - drop_p) : 0.f;
         c.seed = seed;
@@ -316,9 +321,23 @@ static int check_params(const SGLayout &lay, const pcm_stackgru_params *w,
     return PCM_OK;
 }
 
+static int check_active_rows(const int32_t *active_rows, const int32_t *lengths,
+                             int steps, int batch, const char *who) {
+    if (!active_rows) return PCM_OK;
+    PCM_REQUIRE(lengths, PCM_EINVAL, "%s: active_rows needs lengths", who);
+    int prev = batch;
+    for (int t = 0; t < steps; ++t) {
+        PCM_REQUIRE(active_rows[t] >= 0 && active_rows[t] <= prev, PCM_EINVAL,
+                    "%s: active_rows[%d]=%d must lie in [0, %d] (non-increasing, "
+                    "length-sorted batch)", who, t, active_rows[t], prev);
+        prev = active_rows[t];
+    }
+    return PCM_OK;
+}
+
 extern "C" {
 
-int pcm_version(void) { return 1; }
+int pcm_version(void) { return 2; }
 
 int pcm_probe_enable(int32_t kernel_id, int32_t max_launches) {
     PCM_REQUIRE(kernel_id >= 0 && kernel_id <= PCM_K_GEMM, PCM_EINVAL,
@@ -395,11 +414,12 @@ size_t pcm_stackgru_scratch_bytes(const pcm_dims *dims, int32_t steps) {
 int pcm_stackgru_forward(const pcm_dims *dims,
                          const pcm_stackgru_params *weights,
                          const int64_t *tokens, int32_t steps,
-                         const int32_t *lengths, const float *h0,
-                         int64_t h0_layer_stride, const float *stack0,
-                         float dropout_p, uint64_t seed, int32_t training,
-                         void *saved, size_t saved_bytes, float *h_final,
-                         float *stack_final, int32_t *status, void *stream) {
+                         const int32_t *lengths, const int32_t *active_rows,
+                         const float *h0, int64_t h0_layer_stride,
+                         const float *stack0, float dropout_p, uint64_t seed,
+                         int32_t training, void *saved, size_t saved_bytes,
+                         float *h_final, float *stack_final, int32_t *status,
+                         void *stream) {
     SGLayout lay;
     // the layout always reserves the dropout slots so that saved_bytes() does
     // not depend on dropout_p; they are only written when dropout is active
@@ -415,11 +435,36 @@ int pcm_stackgru_forward(const pcm_dims *dims,
                 "stackgru_forward: dropout %f outside [0,1)", dropout_p);
     PCM_REQUIRE(((uintptr_t)saved & 15) == 0, PCM_EINVAL,
                 "stackgru_forward: saved workspace must be 16-byte aligned");
+    rc = check_active_rows(active_rows, lengths, steps, lay.B,
+                           "stackgru_forward");
+    if (rc) return rc;
     const bool drop = training && dropout_p > 0.f && lay.L > 1;
     lay.dropout = drop ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     float *sv = (float *)saved;
 
+    if (active_rows) {
+        // rows past their length are not computed at all: whatever the
+        // time-parallel products of the reverse pass (and the caller's output
+        // layer) read there must be zero, not stale memory
+        const int T = steps, B = lay.B;
+        for (int l = 0; l < lay.L; ++l) {
+            pcm_launch_zero_past_length(sv + lay.off_hs[l], lay.Hp, T, B, 1,
+                                        lengths, st);
+            if (drop && l >= 1)
+                pcm_launch_zero_past_length(sv + lay.off_xdrop[l], lay.Hp, T, B,
+                                            0, lengths, st);
+            if (training)
+                pcm_launch_zero_past_length(sv + lay.off_gates[l], 4 * lay.H, T,
+                                            B, 0, lengths, st);
+        }
+        if (training && lay.use_stack) {
+            pcm_launch_zero_past_length(sv + lay.off_av, lay.AVW, T, B, 0,
+                                        lengths, st);
+            pcm_launch_zero_past_length(sv + lay.off_xtop, lay.Wp, T, B, 0,
+                                        lengths, st);
+        }
+    }
     if (lay.Hp != lay.H) {
         // zero the padding columns of every hidden-state slot once
         for (int l = 0; l < lay.L; ++l)
@@ -460,8 +505,23 @@ int pcm_stackgru_forward(const pcm_dims *dims,
         }
         sb.tok = tokens + (size_t)t * lay.B;
         rc = enqueue_step(lay, weights, sv + lay.off_tokg, wpack, bpack, sb,
-                          lengths, t, dropout_p, seed, status, st);
+                          lengths, t, dropout_p, seed, status, st,
+                          active_rows ? active_rows[t] : -1);
         if (rc) return rc;
+    }
+    if (active_rows) {
+        // each row's state after ITS last step (slot lengths[b])
+        if (h_final)
+            for (int l = 0; l < lay.L; ++l)
+                pcm_launch_gather_at_length(
+                    sv + lay.off_hs[l], (long long)lay.hs_step(), lay.Hp, steps,
+                    0, lengths, h_final + (size_t)l * lay.B * lay.H, lay.H,
+                    lay.B, st);
+        if (stack_final && lay.use_stack)
+            pcm_launch_gather_at_length(
+                sv + lay.off_S, (long long)lay.B * lay.DW, lay.DW, steps,
+                training ? 0 : 1, lengths, stack_final, lay.DW, lay.B, st);
+        return pcm_check_launch("stackgru_forward");
     }
     if (h_final)
         for (int l = 0; l < lay.L; ++l)
@@ -477,8 +537,9 @@ int pcm_stackgru_forward(const pcm_dims *dims,
 int pcm_stackgru_backward(const pcm_dims *dims,
                           const pcm_stackgru_params *weights,
                           const int64_t *tokens, int32_t steps,
-                          const int32_t *lengths, float dropout_p,
-                          uint64_t seed, void *saved, size_t saved_bytes,
+                          const int32_t *lengths, const int32_t *active_rows,
+                          float dropout_p, uint64_t seed, void *saved,
+                          size_t saved_bytes,
                           const float *d_out, int64_t d_out_row_stride,
                           const float *d_h_final, const float *d_stack_final,
                           float *d_h0, float *d_stack0,
@@ -498,6 +559,9 @@ int pcm_stackgru_backward(const pcm_dims *dims,
     PCM_REQUIRE(scratch_bytes >= sc.total * sizeof(float), PCM_ENOMEM,
                 "stackgru_backward: scratch %zu < %zu bytes", scratch_bytes,
                 sc.total * sizeof(float));
+    rc = check_active_rows(active_rows, lengths, steps, lay.B,
+                           "stackgru_backward");
+    if (rc) return rc;
     const bool drop = dropout_p > 0.f && lay.L > 1;
     lay.dropout = drop ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
@@ -518,11 +582,15 @@ int pcm_stackgru_backward(const pcm_dims *dims,
     float *dS[2] = {scf + sc.off_dS, scf + sc.off_dS + (size_t)B * lay.DW};
     int cur = 0;
     if (lay.use_stack) {
-        if (d_stack_final)
-            pcm_launch_copy_rows(d_stack_final, lay.DW, dS[0], lay.DW, B, lay.DW,
-                                 st);
-        else
-            pcm_launch_fill(dS[0], 0.f, (long long)B * lay.DW, st);
+        // (with a shrinking active batch a row joins the walk at its own last
+        // step, in whichever ping-pong slot is current then: seed both)
+        for (int q = 0; q < (active_rows ? 2 : 1); ++q) {
+            if (d_stack_final)
+                pcm_launch_copy_rows(d_stack_final, lay.DW, dS[q], lay.DW, B,
+                                     lay.DW, st);
+            else
+                pcm_launch_fill(dS[q], 0.f, (long long)B * lay.DW, st);
+        }
     }
     float *dtop = scf + sc.off_dtop;
     float *tmp = scf + sc.off_tmp;
@@ -799,7 +867,9 @@ int pcm_stackgru_backward(const pcm_dims *dims,
     };
 
     for (int t = T - 1; t >= 0; --t) {
-        for (int l = L - 1; l >= 0; --l) {
+        // rows still running at step t (length-sorted prefix)
+        const int Bt = active_rows ? active_rows[t] : B;
+        for (int l = L - 1; l >= 0 && Bt > 0; --l) {
             float *gates = sv + lay.off_gates[l] + (size_t)t * B * 4 * H;
             float *dhl = dh + (size_t)l * B * Hp;
             // gate derivatives: the top layer (it also receives d_out and
@@ -816,7 +886,7 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                 g.ld_dout = d_out_row_stride;
                 g.gates = gates;
                 g.hprev = sv + lay.off_hs[l] + (size_t)t * lay.hs_step();
-                g.lengths = lengths; g.B = B; g.H = H; g.Hp = Hp; g.t = t;
+                g.lengths = lengths; g.B = Bt; g.H = H; g.Hp = Hp; g.t = t;
                 if (l == L - 1 && lay.use_stack && t + 1 < T) {
                     g.dcu = sv + lay.av_index(t + 1);
                     g.ctrl_w = weights->ctrl_w; g.push_w = weights->push_w;
@@ -836,7 +906,7 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                 cb.ldx = l > 0 ? Hp : lay.Wp;
                 cb.dx_accumulate = l > 0 ? 1 : 0;
                 cb.dx_cols = l > 0 ? H : lay.Wp;
-                cb.B = B; cb.H = H; cb.Hp = Hp;
+                cb.B = Bt; cb.H = H; cb.Hp = Hp;
                 cb.NT = H + lay.Kxp[l];
                 cb.t = t; cb.layer = l;
                 cb.drop_p = (l > 0 && drop) ? dropout_p : 0.f;
@@ -861,7 +931,7 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             gb.count = 0;
             const bool seg_ok = ((2 * H) % 16) == 0;
             GemmProb p1 = pcm_gemm_prob(gates, 4LL * H, 1, weights->w_hh[l], H,
-                                        1, dhl, Hp, B, H, seg_ok ? 3 * H : 2 * H);
+                                        1, dhl, Hp, Bt, H, seg_ok ? 3 * H : 2 * H);
             p1.accumulate = 1;
             if (seg_ok) {
                 p1.K1 = 2 * H;
@@ -874,14 +944,14 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             if (l > 0) {
                 GemmProb p2 = pcm_gemm_prob(
                     gates, 4LL * H, 1, weights->w_ih[l], H, 1,
-                    use_tmp ? tmp : dh + (size_t)(l - 1) * B * Hp, Hp, B, H,
+                    use_tmp ? tmp : dh + (size_t)(l - 1) * B * Hp, Hp, Bt, H,
                     3 * H);
                 p2.accumulate = use_tmp ? 0 : 1;
                 gb.p[gb.count++] = p2;
             } else if (lay.use_stack) {
                 GemmProb p2 = pcm_gemm_prob(gates, 4LL * H, 1,
                                             weights->w_ih[0] + lay.E, ld0, 1,
-                                            dtop, lay.Wp, B, lay.W, 3 * H);
+                                            dtop, lay.Wp, Bt, lay.W, 3 * H);
                 gb.p[gb.count++] = p2;
             }
             pcm_probe_begin(PCM_K_GEMM, st);
@@ -893,7 +963,7 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                 g2.count = 1;
                 GemmProb p3 = pcm_gemm_prob(gates + 3 * H, 4LL * H, 1,
                                             weights->w_hh[l] + (size_t)2 * H * H,
-                                            H, 1, dhl, Hp, B, H, H);
+                                            H, 1, dhl, Hp, Bt, H, H);
                 p3.accumulate = 1;
                 g2.p[0] = p3;
                 rc = pcm_gemm_launch(g2, gs, gsb, st);
@@ -901,16 +971,16 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             }
             if (use_tmp)
                 pcm_launch_dropout_add(dh + (size_t)(l - 1) * B * Hp, Hp, tmp, Hp,
-                                       B, H, seed, l, t, dropout_p, st);
+                                       Bt, H, seed, l, t, dropout_p, st);
         }
-        if (lay.use_stack) {
+        if (lay.use_stack && Bt > 0) {
             StackBwdArgs s;
             s.dS_next = dS[cur]; s.dS_prev = dS[cur ^ 1];
             s.dtop = dtop;
             s.S_prev = sv + lay.s_index(t);
             s.av = sv + lay.av_index(t);
             s.lengths = lengths;
-            s.B = B; s.H = H; s.Hp = Hp; s.D = lay.D; s.W = lay.W;
+            s.B = Bt; s.H = H; s.Hp = Hp; s.D = lay.D; s.W = lay.W;
             s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
             pcm_probe_begin(PCM_K_STACK_BWD, st);
             pcm_launch_stack_bwd(s, st);

@@ -101,6 +101,16 @@ int pcm_launch_pack(const PackArgs &a, hipStream_t stream);
 int pcm_launch_init_state(const SGLayout &lay, float *saved, const float *h0,
                           long long h0_layer_stride, const float *stack0,
                           hipStream_t stream);
+// packed mode with a shrinking active batch: zero rows (t + slot_off, b),
+// t >= lengths[b], of a [slots][B][width] buffer; gather each row's state at
+// slot lengths[b] (parity != 0: slot lengths[b] & 1 of a two-slot ping-pong)
+int pcm_launch_zero_past_length(float *buf, int width, int T, int B,
+                                int slot_off, const int32_t *lengths,
+                                hipStream_t stream);
+int pcm_launch_gather_at_length(const float *buf, long long slot_floats,
+                                int width, int T, int parity,
+                                const int32_t *lengths, float *out, int cols,
+                                int B, hipStream_t stream);
 // h_final / stack_final extraction (strided copy)
 int pcm_launch_copy_rows(const float *src, long long lds, float *dst,
                          long long ldd, int rows, int cols,

@@ -603,12 +603,52 @@ __global__ __launch_bounds__(256) void fill_kernel(float *dst, float value,
         dst[idx] = value;
 }
 
+// buf is [slots][B][width]; row (t + slot_off, b) is zeroed for t >= lengths[b]
+// (one block per (t, b): most exit at once)
+__global__ __launch_bounds__(256) void zero_past_length_kernel(
+    float *buf, int width, int B, int slot_off, const int32_t *lengths) {
+    const int t = blockIdx.y, b = blockIdx.x;
+    if (t < lengths[b]) return;
+    float *row = buf + ((long long)(t + slot_off) * B + b) * width;
+    for (int j = threadIdx.x; j < width; j += 256) row[j] = 0.f;
+}
+
+// out[b][0..cols) = buf[slot(b)][b][0..cols), slot(b) = min(lengths[b], T)
+// (or its parity when the state ping-pongs between two slots)
+__global__ __launch_bounds__(256) void gather_at_length_kernel(
+    const float *buf, long long slot_floats, int width, int T, int parity,
+    const int32_t *lengths, float *out, int cols) {
+    const int b = blockIdx.x;
+    int slot = min(max(lengths[b], 0), T);
+    if (parity) slot &= 1;
+    const float *row = buf + slot * slot_floats + (long long)b * width;
+    for (int j = threadIdx.x; j < cols; j += 256)
+        out[(long long)b * cols + j] = row[j];
+}
+
 int grid_for(long long n) {
     long long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
 }  // namespace
+
+int pcm_launch_zero_past_length(float *buf, int width, int T, int B,
+                                int slot_off, const int32_t *lengths,
+                                hipStream_t stream) {
+    hipLaunchKernelGGL(zero_past_length_kernel, dim3(B, T), dim3(256), 0, stream,
+                       buf, width, B, slot_off, lengths);
+    return 0;
+}
+
+int pcm_launch_gather_at_length(const float *buf, long long slot_floats,
+                                int width, int T, int parity,
+                                const int32_t *lengths, float *out, int cols,
+                                int B, hipStream_t stream) {
+    hipLaunchKernelGGL(gather_at_length_kernel, dim3(B), dim3(256), 0, stream,
+                       buf, slot_floats, width, T, parity, lengths, out, cols);
+    return 0;
+}
 
 int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
     dim3 grid(a.Hn / CN, (a.B + CM - 1) / CM);

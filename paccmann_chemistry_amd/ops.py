@@ -38,6 +38,32 @@ def check_status(status, what='token ids'):
         raise RuntimeError(f'index out of range in self ({what})')
 
 
+# Packed batches launch over the still-running prefix of the batch (True) or
+# over every row, freezing the finished ones (False; also what happens when
+# the lengths are not sorted).  Both give the same mu / logvar / loss /
+# gradients; tests flip it to keep the frozen-row path covered.
+SHRINK_ACTIVE_BATCH = True
+
+
+def _active_rows(lengths, steps):
+    """Host int32[T] of rows still running at each step, when the lengths
+    (a CPU tensor, as pad_packed_sequence returns them) are sorted by
+    decreasing length -- PackedSequence.batch_sizes, which the reference
+    slices its hidden / stack by (utils/utils.py:226-243).  None otherwise:
+    the kernels then run every row and freeze the finished ones."""
+    if not SHRINK_ACTIVE_BATCH or lengths.device.type != 'cpu':
+        return None
+    lens = lengths.to(torch.int64)
+    if lens.numel() == 0 or bool((lens[1:] > lens[:-1]).any()):
+        return None
+    steps_idx = torch.arange(steps).view(-1, 1)
+    return (lens.view(1, -1) > steps_idx).sum(dim=1).to(torch.int32).contiguous()
+
+
+def _host_ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
 # --------------------------------------------------------------------------
 # StackGRU over a sequence
 # --------------------------------------------------------------------------
@@ -83,12 +109,15 @@ class StackGRUSequenceFn(torch.autograd.Function):
                 h0_stride = batch * hid
         if stack0 is not None:
             stack0 = _f32(stack0, 'stack0').contiguous()
+        active = None
         if lengths is not None:
+            active = _active_rows(lengths, steps)
             lengths = lengths.to(device=dev, dtype=torch.int32).contiguous()
         check(
             lib.pcm_stackgru_forward(
                 ctypes.byref(dims), ctypes.byref(wstruct), ptr(tokens), steps,
-                ptr(lengths), ptr(h0), h0_stride, ptr(stack0),
+                ptr(lengths), _host_ptr(active), ptr(h0), h0_stride,
+                ptr(stack0),
                 float(cfg['dropout']), int(cfg['seed']), training, ptr(saved),
                 nbytes, ptr(h_final), ptr(stack_final), ptr(status),
                 stream_ptr(dev)
@@ -112,6 +141,7 @@ class StackGRUSequenceFn(torch.autograd.Function):
         ctx.saved_buf = saved
         ctx.tokens = tokens
         ctx.lengths = lengths
+        ctx.active = active
         ctx.weights = weights
         ctx.set_materialize_grads(False)
         if stack_final is None:
@@ -170,7 +200,8 @@ class StackGRUSequenceFn(torch.autograd.Function):
         check(
             lib.pcm_stackgru_backward(
                 ctypes.byref(dims), ctypes.byref(wstruct), ptr(ctx.tokens),
-                steps, ptr(ctx.lengths), float(cfg['dropout']),
+                steps, ptr(ctx.lengths), _host_ptr(ctx.active),
+                float(cfg['dropout']),
                 int(cfg['seed']), ptr(saved), saved.numel() * 4, ptr(d_out),
                 d_out_ld, ptr(d_h_final), ptr(d_stack_final), ptr(d_h0),
                 ptr(d_stack0), ctypes.byref(gstruct), 0, ptr(scratch), sbytes,
