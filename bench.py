@@ -50,10 +50,18 @@ def parse():
                     help='sequences per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=128)
+    ap.add_argument('--ragged', action='store_true',
+                    help='secondary workload: packed mode on ragged lengths '
+                         '~N(60,20) clipped to [10,120] (tokens/s counts the '
+                         'real tokens); the default is the fixed-length '
+                         'padded batch BASELINE.json names')
     ap.add_argument('--probe', type=int, default=5,
                     help='kernel id for the roofline probe (5 = reverse fused '
                          'cell, 1 = forward fused cell, 0 = off)')
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.ragged:
+        args.probe = 0   # per-launch FLOPs vary with the active row count
+    return args
 
 
 def cell_flops_per_launch(p, batch):
@@ -125,8 +133,15 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     import torch.distributed as dist
-    if world > 1:
+    # PCM_BENCH_FORCE_DIST=1 runs the N > 1 code path (process group, hook-driven
+    # async all-reduce, barriers, MAX over ranks) in a one-rank RCCL group: the
+    # rehearsal tests/test_gpu_parity.py does on a single GPU
+    use_dist = world > 1 or os.environ.get('PCM_BENCH_FORCE_DIST') == '1'
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', str(rank))
+        os.environ.setdefault('WORLD_SIZE', str(world))
         dist.init_process_group('nccl', device_id=torch.device(
             'cuda', local_rank))
     torch.cuda.set_device(local_rank)
@@ -139,6 +154,8 @@ def main():
     from oracle import weights as W  # synthetic inputs only
 
     p = dict(PARAMS, batch_size=args.batch)
+    if args.ragged:
+        p['batch_mode'] = 'packed'
     torch.manual_seed(1234)
     vae = P.TeacherVAE(P.StackGRUEncoder(p), P.StackGRUDecoder(p)).to(dev)
     vae.train()
@@ -151,8 +168,22 @@ def main():
     keep = torch.bernoulli(torch.full((SEQ_LEN, ), 0.85), generator=g)
     dec_tokens = tokens.clone()
     dec_tokens[(keep == 0).to(dev)] = 1
+    tokens_per_batch = args.batch * SEQ_LEN
+    if args.ragged:
+        lengths = sorted(W.ragged_lengths(args.batch, SEQ_LEN, 4321 + rank),
+                         reverse=True)
+        cpu_tokens = W.synthetic_tokens(SEQ_LEN, args.batch, p['vocab_size'],
+                                        1234 + rank, lengths)
+        cpu_targets = W.shifted_targets(cpu_tokens)
+        pack = torch.nn.utils.rnn.pack_sequence
+        tokens = dec_tokens = pack(
+            [cpu_tokens[:n, b].to(dev) for b, n in enumerate(lengths)])
+        targets = pack(
+            [cpu_targets[:n, b].to(dev) for b, n in enumerate(lengths)])
+        tokens_per_batch = int(sum(lengths))
 
-    buckets = dp.GradientBuckets(vae, overlap=world > 1)
+    buckets = dp.GradientBuckets(vae, overlap=use_dist,
+                                 force_collective=use_dist)
     # torch.optim.Adam's update (training.py:132) as one fused launch per
     # flat bucket (tests/test_gpu_parity.py: test_flat_adam_matches_torch_adam)
     optimizer = dp.FlatAdam(buckets, lr=LR)
@@ -171,7 +202,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -197,7 +228,7 @@ def main():
         lib.pcm_probe_read(ctypes.byref(probe_ms), ctypes.byref(probe_n),
                            ctypes.byref(dropped))
         lib.pcm_probe_enable(0, 0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
@@ -214,7 +245,9 @@ def main():
     assert final_loss == final_loss, 'loss is NaN'
 
     if rank == 0:
-        tokens_per_step = world * args.batch * SEQ_LEN
+        # (ragged: rank 0's token count stands for every rank's, the
+        # length distributions are the same)
+        tokens_per_step = world * tokens_per_batch
         value = tokens_per_step * args.steps / elapsed
         roofline = None
         if args.probe in PROBE_KERNELS and probe_n.value > 0:
@@ -248,7 +281,9 @@ def main():
                 'workload': 'Stack-GRU VAE training step (fwd+bwd+Adam), '
                             f'batch {args.batch}/GPU, seq len {SEQ_LEN}, '
                             'vocab 60 one-hot, H=512, L=2, stack 50x50, '
-                            'latent 256, dropout 0.2, padded mode',
+                            'latent 256, dropout 0.2, ' +
+                            ('packed mode, ragged lengths ~N(60,20) in '
+                             '[10,120]' if args.ragged else 'padded mode'),
                 'global_batch': world * args.batch, 'seq_len': SEQ_LEN,
                 'parallelism': f'dp{world}',
             },
@@ -256,7 +291,7 @@ def main():
             'final_loss': final_loss,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

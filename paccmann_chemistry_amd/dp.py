@@ -36,9 +36,12 @@ class GradientBuckets:
     buffer, so a bucket's gradients are contiguous and no flatten / unflatten
     copies are needed (FlatAdam below does the same for the parameters)."""
 
-    def __init__(self, model, overlap=True):
+    def __init__(self, model, overlap=True, force_collective=False):
         self.model = model
         self.overlap = overlap
+        # issue the all-reduce even in a one-rank group (rehearses the RCCL
+        # path on a single GPU; the sum over one rank is the identity)
+        self.force_collective = force_collective
         dec = [p for n, p in model.named_parameters()
                if n.startswith('decoder.') and p.requires_grad]
         enc = [p for n, p in model.named_parameters()
@@ -92,7 +95,7 @@ class GradientBuckets:
     def _launch(self, bucket):
         size, _ = world()
         flat = self._gather_flat(bucket)
-        if size > 1:
+        if size > 1 or (self.force_collective and dist.is_initialized()):
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
             self._pending.append(work)
         bucket['ready'] = -(1 << 30)  # launched

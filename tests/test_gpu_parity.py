@@ -676,3 +676,29 @@ def test_cpu_tensor_fails_loudly():
     enc = P.StackGRUEncoder(dict(g.params))
     with pytest.raises(PaccmannHipError):
         enc.cpu().encoder_train_step(g.tensor('tokens'))
+
+
+def test_bench_distributed_path_on_one_rank():
+    """bench.py's N > 1 code path (RCCL process group, gradient buckets reduced
+    asynchronously from autograd hooks, barriers, MAX over ranks) rehearsed in
+    a one-rank group on this GPU: same final loss as the plain run."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2',
+           '--warmup', '1', '--batch', '64', '--no-cpu-baseline', '--probe', '0']
+    losses = []
+    for force in ('0', '1'):
+        env = dict(os.environ, PCM_BENCH_FORCE_DIST=force,
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+        for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+            env.pop(key, None)
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True,
+                             timeout=280)
+        assert res.returncode == 0, res.stderr[-2000:]
+        line = json.loads(res.stdout.strip().splitlines()[-1])
+        assert line['n_gpus'] == 1 and line['value'] > 0
+        losses.append(line['final_loss'])
+    assert losses[0] == losses[1]
