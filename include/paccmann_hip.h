@@ -289,6 +289,39 @@ int pcm_adam_step(float *param, const float *grad, float *exp_avg,
                   float beta2, float eps, int64_t step, float grad_scale,
                   void *stream);
 
+/* Batch preparation -----------------------------------------------------------*/
+
+/*
+ * The three training sequences of a batch, built on the device from the
+ * concatenated samples (one host->device copy per batch): what
+ * sequential_data_preparation (utils/utils.py:29-81, after training.py:339-348
+ * pad_sequence) and packed_sequential_data_preparation (utils/utils.py:84-146)
+ * build sample by sample on the host.
+ *
+ *   flat      int64[N]    the samples' tokens back to back
+ *   offsets   int64[B+1]  sample b is flat[offsets[b] .. offsets[b+1])
+ *   steps     T = the longest sample
+ *   packed == 0: enc / dec / tgt are int64[T,B], zero padded.  tgt is enc
+ *            shifted by one step with a zero row appended; word dropout
+ *            replaces WHOLE time rows of dec by dropout_index, padding
+ *            included (utils/utils.py:65-75).
+ *   packed != 0: enc / dec / tgt are the `data` of three PackedSequences,
+ *            element (t, b) at step_base[t] + b, step_base int64[T] = exclusive
+ *            prefix sum of batch_sizes (samples sorted by decreasing length);
+ *            word dropout is per token (utils/utils.py:118-137), tgt is each
+ *            sample shifted by one with a zero appended.
+ *   A token (packed) or time row (padded) is KEPT when keep_mask[i] != 0, i =
+ *   flat position / time step; with keep_mask == NULL when a counter-based
+ *   uniform of (seed, i) is below input_keep (Bernoulli(input_keep), always
+ *   kept at input_keep >= 1).
+ */
+int pcm_prepare_batch(const int64_t *flat, const int64_t *offsets,
+                      int32_t batch, int32_t steps, int32_t packed,
+                      const int64_t *step_base, float input_keep,
+                      uint64_t seed, const uint8_t *keep_mask,
+                      int64_t dropout_index, int64_t *enc, int64_t *dec,
+                      int64_t *tgt, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -104,6 +104,12 @@ PROTOTYPES = {
             _F32, _U64, _VP, _VP, _VP, _SZ, _VP, _VP
         ]
     ),
+    'pcm_prepare_batch': (
+        ctypes.c_int, [
+            _VP, _VP, _I32, _I32, _I32, _VP, _F32, _U64, _VP, _I64, _VP, _VP,
+            _VP, _VP
+        ]
+    ),
     'pcm_adam_step': (
         ctypes.c_int,
         [_VP, _VP, _VP, _VP, _I64, _F32, _F32, _F32, _F32, _I64, _F32, _VP]

@@ -375,6 +375,34 @@ int pcm_launch_broadcast_token(const int64_t *src, int B, int64_t *next_tok,
     return 0;
 }
 
+// encoder / decoder / target sequences of one batch (see pcm_prepare_batch)
+__global__ __launch_bounds__(256) void prepare_batch_kernel(
+    const int64_t *flat, const int64_t *offsets, int B, int T,
+    const int64_t *step_base, float input_keep, uint64_t seed,
+    const uint8_t *keep_mask, int64_t dropout_index, int64_t *enc, int64_t *dec,
+    int64_t *tgt) {
+    const long long total = (long long)T * B;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * 256) {
+        const int t = (int)(idx / B), b = (int)(idx - (long long)t * B);
+        const long long o = offsets[b];
+        const int len = (int)(offsets[b + 1] - o);
+        const bool live = t < len;
+        if (step_base && !live) continue;   // packed data holds live tokens only
+        const int64_t tok = live ? flat[o + t] : 0;
+        const int64_t nxt = t + 1 < len ? flat[o + t + 1] : 0;
+        // dropout unit: the token (packed) or the whole time row (padded)
+        const uint64_t unit = step_base ? (uint64_t)(o + t) : (uint64_t)t;
+        bool keep = true;
+        if (keep_mask) keep = keep_mask[unit] != 0;
+        else if (input_keep < 1.f) keep = pcm_uniform(seed, unit) < input_keep;
+        const long long at = step_base ? step_base[t] + b : idx;
+        enc[at] = tok;
+        dec[at] = keep ? tok : dropout_index;
+        tgt[at] = nxt;
+    }
+}
+
 extern "C" {
 
 int pcm_softmax_ce(const float *logits, const int64_t *targets,
@@ -446,6 +474,26 @@ int pcm_kl_backward(const float *dkl, const float *mu, const float *logvar,
                        (hipStream_t)stream, dkl, mu, logvar, dmu, dlogvar,
                        (long long)n);
     return pcm_check_launch("kl_backward");
+}
+
+int pcm_prepare_batch(const int64_t *flat, const int64_t *offsets,
+                      int32_t batch, int32_t steps, int32_t packed,
+                      const int64_t *step_base, float input_keep,
+                      uint64_t seed, const uint8_t *keep_mask,
+                      int64_t dropout_index, int64_t *enc, int64_t *dec,
+                      int64_t *tgt, void *stream) {
+    PCM_REQUIRE(flat && offsets && enc && dec && tgt, PCM_EINVAL,
+                "prepare_batch: null pointer");
+    PCM_REQUIRE(batch > 0 && steps > 0, PCM_EINVAL,
+                "prepare_batch: bad shape B=%d T=%d", batch, steps);
+    PCM_REQUIRE(!packed || step_base, PCM_EINVAL,
+                "prepare_batch: packed layout needs step_base");
+    const long long total = (long long)steps * batch;
+    hipLaunchKernelGGL(prepare_batch_kernel, dim3(grid_for(total)), dim3(256), 0,
+                       (hipStream_t)stream, flat, offsets, batch, steps,
+                       packed ? step_base : nullptr, input_keep, seed, keep_mask,
+                       dropout_index, enc, dec, tgt);
+    return pcm_check_launch("prepare_batch");
 }
 
 int pcm_adam_step(float *param, const float *grad, float *exp_avg,

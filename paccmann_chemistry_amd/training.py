@@ -16,12 +16,22 @@ from .loss_functions import vae_loss_function
 from .search import SamplingSearch
 from .utils import (
     crop_start_stop, get_device, packed_sequential_data_preparation,
-    sequential_data_preparation, unpack_sequence
+    prepare_batch_on_device, sequential_data_preparation, unpack_sequence
 )
 
 
+def _on_hip(device):
+    device = get_device() if device is None else torch.device(device)
+    return device.type == 'cuda'
+
+
 def _prepare_packed(batch, input_keep, start_index, end_index, device=None):
-    """training.py:328-336."""
+    """training.py:328-336; on a HIP device the three PackedSequences are
+    built by one launch from one staged copy (utils.prepare_batch_on_device)."""
+    if _on_hip(device) and isinstance(batch, (list, tuple)):
+        return prepare_batch_on_device(
+            batch, True, input_keep=input_keep, device=device
+        )
     return packed_sequential_data_preparation(
         batch, input_keep=input_keep, start_index=start_index,
         end_index=end_index, device=device
@@ -29,7 +39,11 @@ def _prepare_packed(batch, input_keep, start_index, end_index, device=None):
 
 
 def _prepare_padded(batch, input_keep, start_index, end_index, device):
-    """training.py:339-348."""
+    """training.py:339-348 (one launch on a HIP device, as above)."""
+    if _on_hip(device) and isinstance(batch, (list, tuple)):
+        return tuple(prepare_batch_on_device(
+            batch, False, input_keep=input_keep, device=device
+        ))
     padded_batch = torch.nn.utils.rnn.pad_sequence(batch).to(device)
     return sequential_data_preparation(
         padded_batch, input_keep=input_keep, start_index=start_index,

@@ -77,6 +77,78 @@ def packed_sequential_data_preparation(
     return [pack_sequence(entry) for entry in (enc, dec, tgt)]
 
 
+def prepare_batch_on_device(
+    batch, packed, input_keep=1, dropout_index=1, device=None, keep_mask=None,
+    seed=None
+):
+    """Both preparations above as ONE host->device copy and ONE launch
+    (pcm_prepare_batch): ``batch`` is the DataLoader's list of 1-D token
+    tensors (for ``packed`` sorted longest first, as ``collate_fn`` leaves it).
+
+    Returns what ``sequential_data_preparation(pad_sequence(batch))`` /
+    ``packed_sequential_data_preparation(batch)`` return: three i64[T,B]
+    tensors, or three PackedSequences.  The Bernoulli word-dropout draws come
+    from a counter hash seeded from torch's global generator (``seed``), or
+    from ``keep_mask`` (uint8: per time step when padded, per token of the
+    concatenated batch when packed) when the caller supplies the draws."""
+    import ctypes
+
+    from . import _lib
+    device = get_device() if device is None else torch.device(device)
+    if device.type != 'cuda':
+        raise _lib.PaccmannHipError(
+            'prepare_batch_on_device needs a HIP device (the host-side '
+            'restatements are sequential_data_preparation / '
+            'packed_sequential_data_preparation)'
+        )
+    samples = []
+    for sample in batch:
+        if sample.dim() != 1:
+            raise ValueError
+        samples.append(sample.long().cpu())
+    lens = torch.tensor([s.shape[0] for s in samples], dtype=torch.int64)
+    if len(samples) == 0 or int(lens.min()) < 1:
+        raise ValueError('empty batch or empty sample')
+    n_batch, steps = len(samples), int(lens.max())
+    offsets = torch.zeros(n_batch + 1, dtype=torch.int64)
+    offsets[1:] = torch.cumsum(lens, 0)
+    parts = [torch.cat(samples), offsets]
+    batch_sizes = None
+    if packed:
+        if bool((lens[1:] > lens[:-1]).any()):
+            raise RuntimeError(
+                '`lengths` array must be sorted in decreasing order when '
+                '`enforce_sorted` is True.'
+            )
+        batch_sizes = (lens.view(1, -1) > torch.arange(steps).view(-1, 1)).sum(1)
+        parts.append(torch.cumsum(batch_sizes, 0) - batch_sizes)
+    staged = torch.cat(parts).to(device, non_blocking=True)
+    total = int(offsets[-1])
+    flat, offs = staged[:total], staged[total:total + n_batch + 1]
+    base = staged[total + n_batch + 1:] if packed else None
+    shape = (total, ) if packed else (steps, n_batch)
+    out = torch.empty((3, ) + shape, dtype=torch.int64, device=device)
+    if keep_mask is not None:
+        need = total if packed else steps
+        keep_mask = keep_mask.to(device=device, dtype=torch.uint8).contiguous()
+        if keep_mask.numel() != need:
+            raise ValueError(f'keep_mask needs {need} entries')
+    if seed is None:
+        seed = int(torch.randint(0, 2**62, (1, )).item())
+    lib = _lib.load()
+    _lib.check(
+        lib.pcm_prepare_batch(
+            _lib.ptr(flat), _lib.ptr(offs), n_batch, steps, 1 if packed else 0,
+            _lib.ptr(base), float(input_keep), ctypes.c_uint64(seed),
+            _lib.ptr(keep_mask), int(dropout_index), _lib.ptr(out[0]),
+            _lib.ptr(out[1]), _lib.ptr(out[2]), _lib.stream_ptr(device)
+        ), 'pcm_prepare_batch'
+    )
+    if not packed:
+        return out[0], out[1], out[2]
+    return [PackedSequence(out[i], batch_sizes) for i in range(3)]
+
+
 def collate_fn(batch):
     """Sort a batch from longest to shortest (utils/utils.py:149-168)."""
     order = sorted(

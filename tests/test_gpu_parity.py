@@ -702,3 +702,69 @@ def test_bench_distributed_path_on_one_rank():
         assert line['n_gpus'] == 1 and line['value'] > 0
         losses.append(line['final_loss'])
     assert losses[0] == losses[1]
+
+
+@pytest.mark.parametrize('packed', [False, True])
+def test_prepare_batch_on_device_matches_host(packed):
+    """pcm_prepare_batch against the host-side restatements of
+    sequential_data_preparation / packed_sequential_data_preparation
+    (utils/utils.py:29-146) with the Bernoulli draws supplied."""
+    from paccmann_chemistry_amd import utils as U
+    rng = np.random.default_rng(5)
+    lens = sorted(rng.integers(1, 40, size=37).tolist(), reverse=True)
+    batch = [torch.from_numpy(rng.integers(2, 60, size=n)) for n in lens]
+    steps, total = max(lens), sum(lens)
+    keep = torch.from_numpy(
+        (rng.random(total if packed else steps) < 0.7).astype(np.uint8))
+    got = U.prepare_batch_on_device(batch, packed, input_keep=0.7,
+                                    device=_dev(), keep_mask=keep)
+    if packed:
+        pad = torch.nn.utils.rnn.pad_packed_sequence
+        # host restatement with the same draws, sample by sample
+        want, off = ([], [], []), 0
+        for s in batch:
+            k = keep[off:off + len(s)].bool()
+            off += len(s)
+            want[0].append(s.clone())
+            want[1].append(torch.where(k, s, torch.ones_like(s)))
+            want[2].append(torch.cat([s[1:], torch.zeros(1, dtype=s.dtype)]))
+        for g, w in zip(got, want):
+            assert isinstance(g, torch.nn.utils.rnn.PackedSequence)
+            ref = torch.nn.utils.rnn.pack_sequence(w)
+            assert torch.equal(g.data.cpu(), ref.data)
+            assert torch.equal(g.batch_sizes, ref.batch_sizes)
+            assert torch.equal(pad(g)[1], pad(ref)[1])
+    else:
+        padded = torch.nn.utils.rnn.pad_sequence(batch)
+        dec = padded.clone()
+        dec[keep == 0] = 1
+        tgt = torch.cat([padded[1:], torch.zeros(1, len(lens),
+                                                 dtype=padded.dtype)])
+        for g, w in zip(got, (padded, dec, tgt)):
+            assert torch.equal(g.cpu(), w)
+
+
+def test_prepare_batch_on_device_bernoulli():
+    """Without supplied draws the word dropout is Bernoulli(input_keep) from a
+    counter hash: rate, determinism under a seed, keep == 1 leaves dec == enc,
+    and get_data_preparation routes list batches through it."""
+    from paccmann_chemistry_amd import utils as U
+    from paccmann_chemistry_amd.training import get_data_preparation
+    batch = [torch.full((200, ), 7) for _ in range(64)]
+    enc, dec, tgt = U.prepare_batch_on_device(batch, True, input_keep=0.8,
+                                              device=_dev(), seed=11)
+    kept = (dec.data == 7).float().mean().item()
+    assert abs(kept - 0.8) < 0.02, kept
+    assert set(dec.data.unique().tolist()) == {1, 7}
+    again = U.prepare_batch_on_device(batch, True, input_keep=0.8,
+                                      device=_dev(), seed=11)
+    assert torch.equal(dec.data, again[1].data)
+    enc, dec, tgt = get_data_preparation('padded')(batch, 1, 2, 3, _dev())
+    assert torch.equal(enc, dec) and enc.shape == (200, 64)
+    assert enc.is_cuda and int(tgt[-1].abs().sum()) == 0
+    enc, dec, tgt = get_data_preparation('padded')(batch, 0.5, 2, 3, _dev())
+    rows = (dec == 1).all(dim=1) | (dec == 7).all(dim=1)
+    assert bool(rows.all())      # whole time rows are dropped, or none
+    with pytest.raises(RuntimeError):
+        U.prepare_batch_on_device([torch.ones(3), torch.ones(5)], True,
+                                  device=_dev())
