@@ -876,7 +876,13 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             // the stack-control path of step t+1) and every layer on the
             // generic path take them in their own launch; on the fused path
             // the lower layers' are taken in the epilogue of the cell above
-            if (l == L - 1 || !fused_bwd) {
+            // (with a stack, the top layer's are taken by the stack adjoint of
+            // step t+1, which produces their last operand; only the first
+            // step walked has no such launch above it)
+            const bool by_stack =
+                l == L - 1 && lay.use_stack && t + 1 < T &&
+                (active_rows ? active_rows[t + 1] : B) > 0;
+            if ((l == L - 1 || !fused_bwd) && !by_stack) {
                 GateBwdArgs g;
                 memset(&g, 0, sizeof(g));
                 g.dh = dhl;
@@ -887,11 +893,6 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                 g.gates = gates;
                 g.hprev = sv + lay.off_hs[l] + (size_t)t * lay.hs_step();
                 g.lengths = lengths; g.B = Bt; g.H = H; g.Hp = Hp; g.t = t;
-                if (l == L - 1 && lay.use_stack && t + 1 < T) {
-                    g.dcu = sv + lay.av_index(t + 1);
-                    g.ctrl_w = weights->ctrl_w; g.push_w = weights->push_w;
-                    g.W = lay.W; g.AVW = lay.AVW;
-                }
                 pcm_probe_begin(PCM_K_GATE_BWD, st);
                 pcm_launch_gate_bwd(g, st);
                 pcm_probe_end(PCM_K_GATE_BWD, st);
@@ -982,6 +983,22 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             s.lengths = lengths;
             s.B = Bt; s.H = H; s.Hp = Hp; s.D = lay.D; s.W = lay.W;
             s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
+            // ... followed by the top layer's gate gradient of step t-1 (or,
+            // at t == 0, the control path into the initial hidden state)
+            s.gate_mode = t > 0 ? 1 : 2;
+            s.gate_B = t > 0 ? (active_rows ? active_rows[t - 1] : B) : Bt;
+            s.g_dh = dh + (size_t)(L - 1) * B * Hp;
+            s.g_dout = (t > 0 && d_out)
+                           ? d_out + (size_t)(t - 1) * B * d_out_row_stride
+                           : nullptr;
+            s.g_ld_dout = d_out_row_stride;
+            s.g_gates = t > 0 ? sv + lay.off_gates[L - 1] +
+                                    (size_t)(t - 1) * B * 4 * H
+                              : nullptr;
+            s.g_hprev = t > 0 ? sv + lay.off_hs[L - 1] +
+                                    (size_t)(t - 1) * lay.hs_step()
+                              : nullptr;
+            s.ctrl_w = weights->ctrl_w; s.push_w = weights->push_w;
             pcm_probe_begin(PCM_K_STACK_BWD, st);
             pcm_launch_stack_bwd(s, st);
             pcm_probe_end(PCM_K_STACK_BWD, st);
@@ -994,17 +1011,6 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             rc = flush_param_grads(t);
             if (rc) return rc;
         }
-    }
-    if (lay.use_stack) {
-        // the control path of step 0 reaches the initial top-layer hidden
-        GateBwdArgs g;
-        memset(&g, 0, sizeof(g));
-        g.dh = dh + (size_t)(L - 1) * B * Hp;
-        g.dcu = sv + lay.av_index(0);
-        g.ctrl_w = weights->ctrl_w; g.push_w = weights->push_w;
-        g.W = lay.W; g.AVW = lay.AVW;
-        g.B = B; g.H = H; g.Hp = Hp; g.t = -1; g.ctrl_only = 1;
-        pcm_launch_gate_bwd(g, st);
     }
     if (d_h0)
         for (int l = 0; l < L; ++l)

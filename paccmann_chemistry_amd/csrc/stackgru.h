@@ -122,12 +122,8 @@ struct GateBwdArgs {
     float *gates;         // [B, 4H] in: r,z,n,ghn ; out: dr,dz,dni,dnh
     const float *hprev;   // [B, Hp]
     const int32_t *lengths;
-    // stack-control path of the step above (top layer only, nullable):
-    // dL/dh_t += dc.Wc + du.Ws with [dc,du] = dcu[b][0..3+W)
-    const float *dcu, *ctrl_w, *push_w;
     long long ld_dout;
-    int B, H, Hp, t, W, AVW;
-    int ctrl_only;        // 1: only add the control path into dh (no gates)
+    int B, H, Hp, t;
 };
 int pcm_launch_gate_bwd(const GateBwdArgs &a, hipStream_t stream);
 
@@ -167,10 +163,21 @@ struct StackBwdArgs {
     float *dS_prev;       // [B, D*W] dL/dS_{t-1}
     const float *dtop;    // [B, Wp] gradient of the stack top fed to layer 0
     const float *S_prev;  // [B, D*W]
-    float *av;            // [B, AVW] in: a,v ; out: dc, du (consumed by the
-                          // top layer's gate_bwd of the step below)
+    float *av;            // [B, AVW] in: a,v ; out: dc, du (kept for the
+                          // time-parallel dWc / dWs products)
     const int32_t *lengths;
     int B, H, Hp, D, W, Wp, AVW, t;
+    // fused gate gradient of the TOP layer at step t-1 (what gate_bwd does in
+    // a launch of its own when there is no stack step above it): gate_mode
+    // 0 = off, 1 = full, 2 = control path only (t == 0: the path reaches the
+    // initial hidden state).  gate_B rows (>= B with a shrinking batch).
+    int gate_mode, gate_B;
+    float *g_dh;             // [B, Hp] running dL/dh of the top layer
+    const float *g_dout;     // [B, g_ld_dout] output gradient of step t-1 / null
+    float *g_gates;          // [B, 4H] saved gates of step t-1 (in place)
+    const float *g_hprev;    // [B, Hp] top-layer hidden before step t-1
+    const float *ctrl_w, *push_w;
+    long long g_ld_dout;
 };
 int pcm_launch_stack_bwd(const StackBwdArgs &a, hipStream_t stream);
 

@@ -6,7 +6,9 @@
 //              feed both the per-step dgates.W products and the time-parallel
 //              weight-gradient GEMMs) and the direct dL/dh_{t-1} = dL/dh_t * z
 //   stack_bwd  adjoint of the push/pop/no-op update, control softmax and push
-//              tanh; adds (dc.Wc + du.Ws) into dL/dh_{t-1} of the top layer
+//              tanh; adds (dc.Wc + du.Ws) into dL/dh_{t-1} of the top layer and
+//              takes that layer's gate gradient of step t-1 right there (its
+//              last operand), saving a launch per step
 #include <stdlib.h>
 
 #include "stackgru.h"
@@ -37,46 +39,24 @@ __device__ __forceinline__ void gate_grad(float d, float *g, int H, int j,
 }
 
 __global__ __launch_bounds__(256) void gate_bwd_kernel(GateBwdArgs a) {
-    // grid: x = blocks of 256 hidden units, y = batch row (wave-uniform row =>
-    // the control gradients of the row are scalar loads)
+    // grid: x = blocks of 256 hidden units, y = batch row.  Launched for the
+    // top layer of the first step walked (and of every step of a model without
+    // a stack), and for every layer on the generic path; elsewhere the gate
+    // gradient rides in the stack adjoint / the reverse cell's epilogue.
     const int b = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= a.H) return;
-    const int NO = 3 + a.W;
     float *dh = a.dh + (long long)b * a.Hp + j;
-    float d = *dh;
-    // the saved gates, h_{t-1} and the output gradient are cold HBM lines:
-    // issue their loads first so the control mat-vec below hides the latency
+    const float d = *dh;
     float *g = a.gates + (long long)b * 4 * a.H;
-    float gr = 0.f, gz = 0.f, gn = 0.f, gh = 0.f, hp = 0.f, dout = 0.f;
-    bool frozen = false;
-    if (!a.ctrl_only) {
-        gr = g[j]; gz = g[a.H + j]; gn = g[2 * a.H + j]; gh = g[3 * a.H + j];
-        hp = a.hprev[(long long)b * a.Hp + j];
-        if (a.dout) dout = a.dout[(long long)b * a.ld_dout + j];
-        frozen = a.lengths && a.t >= a.lengths[b];
-    }
-    if (a.dcu) {
-        // stack-control path of step t+1 (zero for rows frozen there)
-        const float *dc = a.dcu + (long long)b * a.AVW;
-        float s = 0.f;
-#pragma unroll
-        for (int o = 0; o < 3; ++o)
-            s = fmaf(dc[o], a.ctrl_w[(long long)o * a.H + j], s);
-#pragma unroll 16
-        for (int o = 3; o < NO; ++o)
-            s = fmaf(dc[o], a.push_w[(long long)(o - 3) * a.H + j], s);
-        d += s;
-    }
-    if (a.ctrl_only) { *dh = d; return; }
-    if (frozen) {
+    if (a.lengths && a.t >= a.lengths[b]) {
         // frozen row: h_t = h_{t-1}; its output carries no gradient
         g[j] = 0.f; g[a.H + j] = 0.f; g[2 * a.H + j] = 0.f;
         g[3 * a.H + j] = 0.f;
-        *dh = d;
         return;
     }
-    gate_grad_vals(d + dout, gr, gz, gn, gh, hp, g, a.H, j, dh);
+    const float dout = a.dout ? a.dout[(long long)b * a.ld_dout + j] : 0.f;
+    gate_grad(d + dout, g, a.H, j, a.hprev[(long long)b * a.Hp + j], dh);
 }
 
 // One block of 512 threads per BROWS batch rows.  S_{t-1} and dL/dS'_t of the
@@ -100,6 +80,79 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
     float *red = dcu + BROWS * a.AVW;       // [BROWS][3][8] wave partials
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * BROWS;
+
+    // fused top-layer gate gradient of step t-1: its operands are cold HBM
+    // lines, the first column's are fetched with the staging loads below
+    struct GatePre { float d, r, z, n, g, hp, dout; };
+    auto gate_load = [&](int r, int j) -> GatePre {
+        GatePre q = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int b = b0 + r;
+        if (b >= a.gate_B || j >= a.H) return q;
+        q.d = a.g_dh[(long long)b * a.Hp + j];
+        if (a.gate_mode == 1) {
+            const float *g = a.g_gates + (long long)b * 4 * a.H;
+            q.r = g[j]; q.z = g[a.H + j]; q.n = g[2 * a.H + j];
+            q.g = g[3 * a.H + j];
+            q.hp = a.g_hprev[(long long)b * a.Hp + j];
+            if (a.g_dout) q.dout = a.g_dout[(long long)b * a.g_ld_dout + j];
+        }
+        return q;
+    };
+    GatePre gpre[BROWS];
+    if (a.gate_mode) {
+#pragma unroll
+        for (int r = 0; r < BROWS; ++r) gpre[r] = gate_load(r, tid);
+    }
+    // dL/dh_{t-1} += dc.Wc + du.Ws (the stack-control path of this step), then
+    // the gate derivatives in place; needs dcu[] complete and synchronised
+    auto gate_part = [&]() {
+        const int H = a.H, NO = 3 + W;
+        for (int j = tid; j < H; j += BTHREADS) {
+            float s[BROWS];
+#pragma unroll
+            for (int r = 0; r < BROWS; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+                const float w = a.ctrl_w[(long long)o * H + j];
+#pragma unroll
+                for (int r = 0; r < BROWS; ++r)
+                    s[r] = fmaf(dcu[r * a.AVW + o], w, s[r]);
+            }
+#pragma unroll 16
+            for (int o = 3; o < NO; ++o) {
+                const float w = a.push_w[(long long)(o - 3) * H + j];
+#pragma unroll
+                for (int r = 0; r < BROWS; ++r)
+                    s[r] = fmaf(dcu[r * a.AVW + o], w, s[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < BROWS; ++r) {
+                const int b = b0 + r;
+                if (b >= a.gate_B) continue;
+                const GatePre q = j == tid ? gpre[r] : gate_load(r, j);
+                float *dh = a.g_dh + (long long)b * a.Hp + j;
+                const float d = q.d + s[r];
+                if (a.gate_mode == 2) { *dh = d; continue; }
+                float *g = a.g_gates + (long long)b * 4 * H;
+                if (a.lengths && a.t - 1 >= a.lengths[b]) {
+                    // frozen row: h_t = h_{t-1}; its output carries no gradient
+                    g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f;
+                    g[3 * H + j] = 0.f;
+                    *dh = d;
+                    continue;
+                }
+                gate_grad_vals(d + q.dout, q.r, q.z, q.n, q.g, q.hp, g, H, j, dh);
+            }
+        }
+    };
+    if (b0 >= a.B) {
+        // rows that finish at step t-1 (shrinking active batch): no stack step
+        // at t, hence no control path -- the gate gradient only
+        for (int idx = tid; idx < BROWS * a.AVW; idx += BTHREADS) dcu[idx] = 0.f;
+        __syncthreads();
+        gate_part();
+        return;
+    }
 
     if ((DW & 3) == 0) {
         const int nq = DW >> 2;
@@ -224,6 +277,7 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
         const int b = b0 + r;
         if (b < a.B) a.av[(long long)b * a.AVW + o] = dcu[idx];
     }
+    if (a.gate_mode) gate_part();
 }
 
 
@@ -622,11 +676,12 @@ int pcm_launch_stack_bwd(const StackBwdArgs &a, hipStream_t stream) {
     }();
     // one row per block while that is at most two blocks per CU (batch 512:
     // 8.2 us against 9.5 for two rows), else two
-    if (a.B <= 2 * cus)
-        hipLaunchKernelGGL(stack_bwd_kernel<1>, dim3(a.B), dim3(BTHREADS),
+    const int rows = a.gate_mode ? (a.gate_B > a.B ? a.gate_B : a.B) : a.B;
+    if (rows <= 2 * cus)
+        hipLaunchKernelGGL(stack_bwd_kernel<1>, dim3(rows), dim3(BTHREADS),
                            row_bytes, stream, a);
     else
-        hipLaunchKernelGGL(stack_bwd_kernel<2>, dim3((a.B + 1) / 2),
+        hipLaunchKernelGGL(stack_bwd_kernel<2>, dim3((rows + 1) / 2),
                            dim3(BTHREADS), 2 * row_bytes, stream, a);
     return 0;
 }
