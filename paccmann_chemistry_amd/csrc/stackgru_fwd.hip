@@ -80,6 +80,42 @@ __device__ __forceinline__ void raw_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
+// Gate math of one (batch row, hidden unit) from its four raw sums
+// s = {r, z, n (input side), n (hidden side)}: token-gate gather, biases,
+// sigma / tanh, (h - n) z + n, length freeze, gate save, dropout of the next
+// layer's input.
+__device__ __forceinline__ void cell_fwd_element(const CellFwdArgs &a, int b,
+                                                 int j, const float (&s)[4]) {
+    const int H = a.H, Hn = a.Hn;
+    float tr = 0.f, tz = 0.f, tn = 0.f;
+    if (a.tokg) {
+        long long tk = a.tok[b];
+        if (tk < 0 || tk >= a.V) {
+            tk = tk < 0 ? 0 : a.V - 1;
+            if (a.status) atomicOr(a.status, PCM_STATUS_BAD_TOKEN);
+        }
+        const float *tg = a.tokg + tk * (3LL * Hn);
+        tr = tg[j]; tz = tg[Hn + j]; tn = tg[2 * Hn + j];
+    }
+    const float r_ = pcm_sigmoid(s[0] + a.bpack[j] + tr);
+    const float z_ = pcm_sigmoid(s[1] + a.bpack[Hn + j] + tz);
+    const float ghn = s[3] + a.bpack[3 * Hn + j];
+    const float n_ = tanhf(s[2] + a.bpack[2 * Hn + j] + tn + r_ * ghn);
+    const float hp = a.hprev[(long long)b * a.Hp + j];
+    // ATen GRU cell: (h - n) * z + n
+    float hn = __fadd_rn(__fmul_rn(hp - n_, z_), n_);
+    if (a.lengths && a.t >= a.lengths[b]) hn = hp;
+    a.hnew[(long long)b * a.Hp + j] = hn;
+    if (a.gates) {
+        float *g = a.gates + (long long)b * 4 * H;
+        g[j] = r_; g[H + j] = z_; g[2 * H + j] = n_; g[3 * H + j] = ghn;
+    }
+    if (a.xdrop)
+        a.xdrop[(long long)b * a.Hp + j] =
+            hn * pcm_dropout_scale(a.seed, a.next_layer, a.t, b, j, a.drop_p,
+                                   a.inv_keep);
+}
+
 // Cross-wave reduction of the four K-slice partials through LDS, then the GRU
 // cell epilogue for the 32 x 32 tile (two outputs per thread).
 __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
@@ -105,7 +141,7 @@ __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
     }
     __syncthreads();
 
-    const int H = a.H, Hn = a.Hn;
+    const int H = a.H;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int e = tid + 512 * q;
@@ -120,33 +156,7 @@ __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
             s[tl] = v;
         }
         if (b >= a.B || j >= H) continue;
-        float tr = 0.f, tz = 0.f, tn = 0.f;
-        if (a.tokg) {
-            long long tk = a.tok[b];
-            if (tk < 0 || tk >= a.V) {
-                tk = tk < 0 ? 0 : a.V - 1;
-                if (a.status) atomicOr(a.status, PCM_STATUS_BAD_TOKEN);
-            }
-            const float *tg = a.tokg + tk * (3LL * Hn);
-            tr = tg[j]; tz = tg[Hn + j]; tn = tg[2 * Hn + j];
-        }
-        const float r_ = pcm_sigmoid(s[0] + a.bpack[j] + tr);
-        const float z_ = pcm_sigmoid(s[1] + a.bpack[Hn + j] + tz);
-        const float ghn = s[3] + a.bpack[3 * Hn + j];
-        const float n_ = tanhf(s[2] + a.bpack[2 * Hn + j] + tn + r_ * ghn);
-        const float hp = a.hprev[(long long)b * a.Hp + j];
-        // ATen GRU cell: (h - n) * z + n
-        float hn = __fadd_rn(__fmul_rn(hp - n_, z_), n_);
-        if (a.lengths && a.t >= a.lengths[b]) hn = hp;
-        a.hnew[(long long)b * a.Hp + j] = hn;
-        if (a.gates) {
-            float *g = a.gates + (long long)b * 4 * H;
-            g[j] = r_; g[H + j] = z_; g[2 * H + j] = n_; g[3 * H + j] = ghn;
-        }
-        if (a.xdrop)
-            a.xdrop[(long long)b * a.Hp + j] =
-                hn * pcm_dropout_scale(a.seed, a.next_layer, a.t, b, j,
-                                       a.drop_p, a.inv_keep);
+        cell_fwd_element(a, b, j, s);
     }
 }
 
@@ -257,6 +267,200 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
     }
     cell_fwd_tail(a, lds, acc_r, acc_z, acc_ni, acc_nh, tid, wave, lrow, lh, j0,
                   b0);
+}
+
+
+// ------------------------------------------------------------------------------
+// narrow fused GRU cell: 32 batch rows x 16 hidden units per block
+// ------------------------------------------------------------------------------
+// Half the work of the 32 x 32 tile per block, for launches that would otherwise
+// give each CU at most one block: twice the blocks, two per CU.  Same loader /
+// consumer split and LDS-DMA staging; the consumers use 16x16x4 MFMAs -- wave w
+// owns the 16-row half (w & 1) of the tile and the half (w >> 1) of every
+// 64-wide chunk's K, for all three gates -- so no column of an MFMA tile is
+// wasted on the n gate's split accumulation (a 32-wide MFMA tile over 16 hidden
+// units would spend a third more MFMA work).  The two K halves meet in LDS, each
+// wave finishing two of its four output rows per lane.
+constexpr int NCN = 16;                         // hidden units per block
+constexpr int NROWS = CM + 3 * NCN;             // stage rows (80)
+constexpr int NSTAGE = NROWS * CK;              // floats per stage (20 KiB)
+constexpr int NNSTAGE = 2;
+constexpr int NNI = NROWS / 16;                 // DMA instructions per loader wave
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void glds5(const char *const (&base)[5],
+                                      const uint32_t (&off)[5],
+                                      uint32_t lds_byte) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %7, %2\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %8, %3\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %9, %4\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %10, %5\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %11, %6\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_byte), "s"(base[0]), "s"(base[1]), "s"(base[2]), "s"(base[3]),
+          "s"(base[4]), "v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]),
+          "v"(off[4])
+        : "memory", "scc");
+}
+
+__global__ __launch_bounds__(512) void gru_cell_fwd16_kernel(CellFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[NNSTAGE * NSTAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j0 = blockIdx.x * NCN;
+    const int b0 = blockIdx.y * CM;
+    const int nchunks = a.nx_chunks + a.nh_chunks;
+    const int last = nchunks - 1;
+
+    f32x4v acc_r = {0.f, 0.f, 0.f, 0.f}, acc_z = acc_r, acc_ni = acc_r,
+           acc_nh = acc_r;
+
+    if (wave >= 4) {
+        // loaders: wave lw issues instructions 5 lw .. 5 lw + 4 of a chunk;
+        // instruction q fills stage rows 4q .. 4q+3 (rows 0-31: activations,
+        // 32-79: the r, z, n weight rows of the 16 hidden units); lane ->
+        // (row 4q + lane / 16, swizzled granule)
+        const int lw = wave - 4;
+        const char *xb = (const char *)a.xin, *hb = (const char *)a.hprev;
+        const char *wb = (const char *)a.wpack;
+        uint32_t offx[NNI], offh[NNI];
+        bool is_a[NNI];
+#pragma unroll
+        for (int i = 0; i < NNI; ++i) {
+            const int q = lw * NNI + i;
+            const int row = 4 * q + (lane >> 4);
+            const int g = (lane & 15) ^ (row & 15);
+            is_a[i] = q < CM / 4;
+            if (is_a[i]) {
+                const int b = min(b0 + row, a.B - 1);
+                offx[i] = (uint32_t)(b * a.ldx + g * 4) * 4u;
+                offh[i] = (uint32_t)(b * a.Hp + g * 4) * 4u;
+            } else {
+                const int wr = row - CM, gate = wr >> 4, jj = wr & 15;
+                offx[i] = (uint32_t)((gate * a.Hn + j0 + jj) * a.Kp + g * 4) * 4u;
+                offh[i] = offx[i];
+            }
+        }
+        const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(size_t)(__attribute__((address_space(3))) void *)lds);
+        auto issue = [&](int cc) {
+            const int c = min(cc, last);
+            const bool xpart = c < a.nx_chunks;
+            const char *abase = xpart ? xb + c * (CK * 4)
+                                      : hb + (c - a.nx_chunks) * (CK * 4);
+            const char *base[NNI];
+            uint32_t off[NNI];
+#pragma unroll
+            for (int i = 0; i < NNI; ++i) {
+                base[i] = is_a[i] ? abase : wb + c * (CK * 4);
+                off[i] = xpart ? offx[i] : offh[i];
+            }
+            glds5(base, off,
+                  lds0 + ((cc % NNSTAGE) * NSTAGE + lw * NNI * 256) * 4u);
+        };
+        issue(0); issue(1);
+        for (int k = 0; k < nchunks; ++k) {
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // chunk k landed
+            raw_barrier();   // A_k: the consumers may read chunk k
+            raw_barrier();   // B_k: they hold its fragments, the stage is free
+            issue(k + 2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        // consumers: lane (r16, g) of wave (rh, kh) reads, for s = 0, 1, the
+        // 16-byte granule 8 kh + 4 s + g of its row: four consecutive k, one
+        // per MFMA e, whose four lane groups together cover 16 of K
+        const int r16 = lane & 15, g = lane >> 4;
+        const int rh = wave & 1, kh = wave >> 1;
+        int slot_a[2], slot_w[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int gran = 8 * kh + 4 * s + g;
+            const int ra = rh * 16 + r16;           // activation row
+            slot_a[s] = ra * CK + ((gran ^ (ra & 15)) << 2);
+            // weight rows CM + 16 gate + r16: (row & 15) == r16 for every gate
+            slot_w[s] = (CM + r16) * CK + ((gran ^ r16) << 2);
+        }
+        auto chunk = [&](int c, f32x4v &acc_n) {
+            f32x4v fa[2], fr[2], fz[2], fn[2];
+            raw_barrier();   // A_c
+            const float *As = lds + (c % NNSTAGE) * NSTAGE;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                fa[s] = *(const f32x4v *)(As + slot_a[s]);
+                fr[s] = *(const f32x4v *)(As + slot_w[s]);
+                fz[s] = *(const f32x4v *)(As + 1 * NCN * CK + slot_w[s]);
+                fn[s] = *(const f32x4v *)(As + 2 * NCN * CK + slot_w[s]);
+            }
+            raw_barrier();   // B_c (waits for the fragment reads first)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc_r = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        fa[s][e], fr[s][e], acc_r, 0, 0, 0);
+                    acc_z = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        fa[s][e], fz[s][e], acc_z, 0, 0, 0);
+                    acc_n = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        fa[s][e], fn[s][e], acc_n, 0, 0, 0);
+                }
+        };
+        for (int c = 0; c < a.nx_chunks; ++c) chunk(c, acc_ni);
+        for (int c = a.nx_chunks; c < nchunks; ++c) chunk(c, acc_nh);
+    }
+
+    // The two K halves of a 16-row half meet in LDS: lane element e (row
+    // 4 g + e of the half, column r16) is finished by wave kh == (e >> 1), so
+    // each consumer wave parks the two rows it does not finish and all four
+    // run the gate math, two elements per lane.
+    __syncthreads();
+    float *red = lds;   // [wave][pair p][tile][lane]
+    if (wave < 4) {
+        const int kh = wave >> 1;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int e = 2 * (1 - kh) + p;   // rows finished by the other wave
+            float *dst = red + ((wave * 2 + p) * 4) * 64 + lane;
+            dst[0 * 64] = acc_r[e]; dst[1 * 64] = acc_z[e];
+            dst[2 * 64] = acc_ni[e]; dst[3 * 64] = acc_nh[e];
+        }
+    }
+    __syncthreads();
+    if (wave < 4) {
+        const int r16 = lane & 15, g = lane >> 4;
+        const int rh = wave & 1, kh = wave >> 1;
+        const int other = wave ^ 2;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int e = 2 * kh + p;          // rows this wave finishes
+            const float *src = red + ((other * 2 + p) * 4) * 64 + lane;
+            // partial of the K half 0 first, then half 1 (a fixed order)
+            float s[4], mine[4] = {acc_r[e], acc_z[e], acc_ni[e], acc_nh[e]};
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl)
+                s[tl] = kh == 0 ? mine[tl] + src[tl * 64]
+                                : src[tl * 64] + mine[tl];
+            const int b = b0 + rh * 16 + 4 * g + e, j = j0 + r16;
+            if (b >= a.B || j >= a.H) continue;
+            cell_fwd_element(a, b, j, s);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------
@@ -652,8 +856,28 @@ int pcm_launch_gather_at_length(const float *buf, long long slot_floats,
 }
 
 int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
-    dim3 grid(a.Hn / CN, (a.B + CM - 1) / CM);
-    hipLaunchKernelGGL(gru_cell_fwd_kernel, grid, dim3(512), 0, stream, a);
+    static const int force = [] {
+        const char *e = getenv("PCM_FWD_TILE");   // 16 / 32: force a tile width
+        return e ? atoi(e) : 0;
+    }();
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess)
+            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount,
+                                        dev);
+        return n;
+    }();
+    const int nbt = (a.B + CM - 1) / CM;
+    // narrow tiles once the wide ones leave half of the CUs without a block
+    // (at exactly one wide block per CU the two run alike: 16.5 against 15.5 us)
+    const bool narrow = force ? force == 16 : 2 * (a.Hn / CN) * nbt <= cus;
+    if (narrow) {
+        dim3 grid(a.Hn / NCN, nbt);
+        hipLaunchKernelGGL(gru_cell_fwd16_kernel, grid, dim3(512), 0, stream, a);
+    } else {
+        dim3 grid(a.Hn / CN, nbt);
+        hipLaunchKernelGGL(gru_cell_fwd_kernel, grid, dim3(512), 0, stream, a);
+    }
     return 0;
 }
 
