@@ -199,7 +199,10 @@ int pcm_sg_scratch(const SGLayout &lay, SGScratch *o) {
     size_t off = 0;
     o->off_dh = take(off, (size_t)lay.L * lay.B * lay.Hp);
     o->off_dS = take(off, (size_t)2 * lay.B * (lay.use_stack ? lay.DW : 1));
-    o->off_dtop = take(off, (size_t)lay.B * (lay.use_stack ? lay.Wp : 1));
+    // (up to H / Wp K-part partials of the stack-top gradient)
+    o->off_dtop = take(off, (size_t)lay.B * (lay.use_stack
+                                ? (size_t)lay.Wp * std::max(1, lay.H / lay.Wp)
+                                : 1));
     o->off_onehot = take(off, (size_t)lay.T * lay.B * lay.V);
     o->off_dtokg = take(off, (size_t)lay.V * 3 * lay.H);
     o->off_tmp = take(off, (size_t)lay.B * lay.Hp);
@@ -869,6 +872,7 @@ int pcm_stackgru_backward(const pcm_dims *dims,
     for (int t = T - 1; t >= 0; --t) {
         // rows still running at step t (length-sorted prefix)
         const int Bt = active_rows ? active_rows[t] : B;
+        int dtop_parts = 1;
         for (int l = L - 1; l >= 0 && Bt > 0; --l) {
             float *gates = sv + lay.off_gates[l] + (size_t)t * B * 4 * H;
             float *dhl = dh + (size_t)l * B * Hp;
@@ -915,12 +919,14 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                 cb.seed = seed;
                 cb.gates_low = nullptr; cb.hprev_low = nullptr;
                 cb.lengths = lengths;
+                cb.xparts = 1; cb.xpart_stride = (long long)B * lay.Wp;
                 if (l > 0) {
                     cb.gates_low = sv + lay.off_gates[l - 1] +
                                    (size_t)t * B * 4 * H;
                     cb.hprev_low = sv + lay.off_hs[l - 1] +
                                    (size_t)t * lay.hs_step();
                 }
+                if (l == 0) dtop_parts = pcm_cell_bwd_xparts(cb);
                 pcm_probe_begin(PCM_K_GEMM, st);
                 pcm_launch_cell_bwd(cb, st);
                 pcm_probe_end(PCM_K_GEMM, st);
@@ -978,6 +984,8 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             StackBwdArgs s;
             s.dS_next = dS[cur]; s.dS_prev = dS[cur ^ 1];
             s.dtop = dtop;
+            s.dtop_parts = dtop_parts;
+            s.dtop_stride = (long long)B * lay.Wp;
             s.S_prev = sv + lay.s_index(t);
             s.av = sv + lay.av_index(t);
             s.lengths = lengths;

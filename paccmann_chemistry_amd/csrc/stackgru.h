@@ -140,6 +140,8 @@ struct CellBwdArgs {
     int ldx, dx_accumulate, dx_cols;
     int B, H, Hp, NT;     // NT = H + Kxp rows of wpackT
     int reg_cols, reg_rows;  // tile region per XCD (set by the launcher)
+    int xparts;              // K-part partials of dx (set by the launcher)
+    long long xpart_stride;  // floats between partials of dx (>= B_total * ldx)
     int t, layer;
     float drop_p, inv_keep;  // drop_p > 0: mask dx with the forward's dropout
     uint64_t seed;
@@ -150,6 +152,9 @@ struct CellBwdArgs {
     const int32_t *lengths;
 };
 int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream);
+// how many partials (stride xpart_stride, to be summed in order) that launch
+// leaves dx in; 1 = the plain result
+int pcm_cell_bwd_xparts(const CellBwdArgs &a);
 
 struct PackTArgs {
     const float *w_ih, *w_hh;
@@ -161,7 +166,10 @@ int pcm_launch_packT(const PackTArgs &a, hipStream_t stream);
 struct StackBwdArgs {
     const float *dS_next; // [B, D*W] dL/dS'_t (null = zeros)
     float *dS_prev;       // [B, D*W] dL/dS_{t-1}
-    const float *dtop;    // [B, Wp] gradient of the stack top fed to layer 0
+    const float *dtop;    // [B, Wp] gradient of the stack top fed to layer 0,
+                          // as dtop_parts partials dtop_stride floats apart
+    int dtop_parts;
+    long long dtop_stride;
     const float *S_prev;  // [B, D*W]
     float *av;            // [B, AVW] in: a,v ; out: dc, du (kept for the
                           // time-parallel dWc / dWs products)

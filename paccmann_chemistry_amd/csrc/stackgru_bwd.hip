@@ -145,6 +145,29 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
             }
         }
     };
+    // the stack-top gradient (the reverse cell may leave it as K-part partials,
+    // summed here in order): fetched with the first loads, used after staging
+    auto dtop_sum = [&](int r, int w) -> float {
+        const int b = b0 + r;
+        if (b >= a.B || w >= W) return 0.f;
+        const float *src = a.dtop + (long long)b * a.Wp + w;
+        // all partials in flight at once (a rolled loop would wait for each)
+        constexpr int PMAX = 16;
+        float part[PMAX];
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p)
+            part[p] = p < a.dtop_parts ? src[p * a.dtop_stride] : 0.f;
+        float v = part[0];
+#pragma unroll
+        for (int p = 1; p < PMAX; ++p) v += part[p];
+        for (int p = PMAX; p < a.dtop_parts; ++p) v += src[p * a.dtop_stride];
+        return v;
+    };
+    float dtop_pre = 0.f;
+    if (tid < BROWS * W) {
+        const int r = pcm_fdiv(tid, inv_W);
+        dtop_pre = dtop_sum(r, tid - r * W);
+    }
     if (b0 >= a.B) {
         // rows that finish at step t-1 (shrinking active batch): no stack step
         // at t, hence no control path -- the gate gradient only
@@ -189,7 +212,7 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
         const int r = pcm_fdiv(idx, inv_W), w = idx - r * W;
         const int b = b0 + r;
         if (b < a.B && !(a.lengths && a.t >= a.lengths[b]))
-            Grow[r * DWp + w] += a.dtop[(long long)b * a.Wp + w];
+            Grow[r * DWp + w] += idx == tid ? dtop_pre : dtop_sum(r, w);
     }
     __syncthreads();
 
@@ -361,12 +384,20 @@ __device__ __forceinline__ void raw_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
-template <int BCN, int BNSTAGE>
+// XPART (narrow tiles, layer 0): the grid holds the hidden-side column tiles
+// only, and the input-side product -- the stack-top gradient, Kxp columns, which
+// as tiles of its own would put a second block on 1/8 of the CUs and double the
+// launch's MFMA time there -- is spread over them instead: block (column tile
+// ct) adds, after its own K loop, the product of K part ct / ncx and input-side
+// column tile ct % ncx (ncx = Kxp / 32) in a second accumulator and stores it
+// as partial number ct / ncx; the stack adjoint sums the partials in order.
+template <int BCN, int BNSTAGE, bool XPART = false>
 __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
+    static_assert(!XPART || BCN == 32, "XPART rides on the narrow tile");
     constexpr int BSTAGE = (BCM + BCN) * BCK;    // floats per LDS stage
     constexpr int BCELL_LDS = BNSTAGE * BSTAGE;  // 48 / 32 KiB
-    constexpr int NTL = BCN / 32;                // MFMA tiles per block
-    constexpr int NQ = BCN / 16;                 // epilogue outputs per thread
+    constexpr int NTL = XPART ? 2 : BCN / 32;    // accumulator tiles per block
+    constexpr int NQ = NTL * 2;                  // epilogue outputs per thread
     constexpr int NI = (BCM + BCN) / 16;         // DMA instructions per loader wave
     static_assert(BCELL_LDS >= 4 * NTL * 1024, "reduction buffer must fit");
     __shared__ __attribute__((aligned(16))) float lds[BCELL_LDS];
@@ -382,13 +413,18 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
     const int sc_ = slot % a.reg_cols, sr_ = slot / a.reg_cols;
     const int ct = (xcd & 3) * a.reg_cols + sc_;          // column tile
     const int bt = (xcd >> 2) * a.reg_rows + sr_;         // batch tile
-    if (ct >= a.NT / BCN || bt * BCM >= a.B) return;
+    if (ct >= (XPART ? a.H : a.NT) / BCN || bt * BCM >= a.B) return;
     const int n0 = ct * BCN;   // first output column (row of wpackT)
     const int b0 = bt * BCM;
     const int H = a.H, K3 = 3 * H;
     const bool hidden_side = n0 < H;   // tile of dh[l] (uses dnh) or of dx (dni)
     const int nchunks = K3 / BCK;
-    const int last = nchunks - 1;
+    // XPART: xcpp extra chunks, K part xkp of input-side column tile xct
+    const int ncx = XPART ? (a.NT - H) / 32 : 1;
+    const int xct = ct % ncx, xkp = ct / ncx;
+    const int xcpp = XPART ? nchunks / a.xparts : 0;
+    const int ntot = nchunks + xcpp;
+    const int last = ntot - 1;
     const int lrow = lane & 31, lh = lane >> 5;
 
     f32x16 acc0, acc1;
@@ -414,6 +450,7 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
         const int b = min(b0 + (ee >> 5), a.B - 1);
         const int n = n0 + tl * 32 + (ee & 31);
         pre_d[q] = pre_r[q] = pre_z[q] = pre_n[q] = pre_g[q] = pre_h[q] = 0.f;
+        if (XPART && tl == 1) continue;   // a partial product: nothing to add to
         if (hidden_side) {
             pre_d[q] = a.dh[(long long)b * a.Hp + n];
         } else {
@@ -436,7 +473,7 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
         // lane -> (row 4q + lane/16, granule slot lane%16)
         const int lw = wave - 4;
         const char *gb = (const char *)a.dgates, *wb = (const char *)a.wpackT;
-        uint32_t off[NI];
+        uint32_t off[NI], offx[NI];
         bool is_a[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -448,16 +485,21 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
                 // rows past the batch re-read the last row (never stored)
                 const int b = min(b0 + row, a.B - 1);
                 off[i] = (uint32_t)(b * 4 * H + g * 4) * 4u;
+                offx[i] = off[i];
             } else {
                 off[i] = (uint32_t)((n0 + row - BCM) * K3 + g * 4) * 4u;
+                offx[i] =
+                    (uint32_t)((H + xct * 32 + row - BCM) * K3 + g * 4) * 4u;
             }
         }
         const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
             (uint32_t)(size_t)(__attribute__((address_space(3))) void *)lds);
         auto issue = [&](int cc) {
-            const int kb = min(cc, last) * BCK;  // the tail re-reads the last chunk
+            const int c = min(cc, last);         // the tail re-reads the last chunk
+            const bool extra = XPART && c >= nchunks;
+            const int kb = (extra ? xkp * xcpp + c - nchunks : c) * BCK;
             // dgates columns: [0,2H) shared; third segment dni at 2H, dnh at 3H
-            const int acol = (kb >= 2 * H && hidden_side) ? kb + H : kb;
+            const int acol = (kb >= 2 * H && hidden_side && !extra) ? kb + H : kb;
             const char *base[NI];
 #pragma unroll
             for (int i = 0; i < NI; ++i)
@@ -465,11 +507,12 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
             const uint32_t dst =
                 lds0 + ((cc % BNSTAGE) * BSTAGE + lw * NI * 256) * 4u;
             if constexpr (NI == 6) glds6(base, off, dst);
+            else if (extra) glds4(base, offx, dst);
             else glds4(base, off, dst);
         };
 #pragma unroll
         for (int c = 0; c < BNSTAGE; ++c) issue(c);
-        for (int k = 0; k < nchunks; ++k) {
+        for (int k = 0; k < ntot; ++k) {
             // chunk k landed (the newest BNSTAGE - 1 chunks may be in flight)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (BNSTAGE - 1)) : "memory");
             raw_barrier();   // A_k: the consumers may read chunk k
@@ -488,7 +531,7 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
         // two barriers per chunk, one fragment set: a simpler, smaller kernel
         // measured faster than the deeper pipeline (four stages, fragment
         // double buffer) it replaced -- the MFMA loop is at its issue bound
-        for (int c = 0; c < nchunks; ++c) {
+        auto chunk = [&](int c, f32x16 &acc_main) {
             f32x4 fa[2], f0[2], f1[2];
             raw_barrier();   // A_c
             const float *As = lds + (c % BNSTAGE) * BSTAGE;
@@ -496,7 +539,7 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
             for (int s = 0; s < 2; ++s) {
                 fa[s] = *(const f32x4 *)(As + slot[s]);
                 f0[s] = *(const f32x4 *)(As + BCM * BCK + slot[s]);
-                if constexpr (NTL == 2)
+                if constexpr (BCN == 64)
                     f1[s] = *(const f32x4 *)(As + (BCM + 32) * BCK + slot[s]);
             }
             raw_barrier();   // B_c (waits for the fragment reads first)
@@ -504,13 +547,17 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                        fa[s][e], f0[s][e], acc0, 0, 0, 0);
-                    if constexpr (NTL == 2)
+                    acc_main = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[s][e], f0[s][e], acc_main, 0, 0, 0);
+                    if constexpr (BCN == 64)
                         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(
                             fa[s][e], f1[s][e], acc1, 0, 0, 0);
                 }
-        }
+        };
+        // two straight loops so that each accumulator is updated in place
+        for (int c = 0; c < nchunks; ++c) chunk(c, acc0);
+        if constexpr (XPART)
+            for (int c = nchunks; c < ntot; ++c) chunk(c, acc1);
     }
 
     __syncthreads();
@@ -536,6 +583,14 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
         for (int w = 0; w < 4; ++w) v += red[(w * NTL + tl) * 1024 + ee];
         const int b = b0 + row, n = n0 + tl * 32 + col;
         if (b >= a.B) continue;
+        if (XPART && tl == 1) {
+            // partial xkp of the input-side gradient (stack top: no dropout,
+            // no layer below)
+            const int j = xct * 32 + col;
+            if (j < a.dx_cols)
+                a.dx[(long long)xkp * a.xpart_stride + (long long)b * a.ldx + j] = v;
+            continue;
+        }
         if (hidden_side) {
             a.dh[(long long)b * a.Hp + n] = pre_d[q] + v;
         } else {
@@ -622,15 +677,7 @@ int pcm_launch_gate_bwd(const GateBwdArgs &a, hipStream_t stream) {
     return 0;
 }
 
-int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream) {
-    // Narrow (32-column) tiles with a third LDS stage when the wide ones would
-    // give each CU at most one block: the per-block MFMA time halves and two
-    // blocks share a CU (measured 29.4 -> 28.7 ms per training step at batch
-    // 512).  PCM_BWD_TILE=32|64 forces a width.
-    static const int force = [] {
-        const char *e = getenv("PCM_BWD_TILE");
-        return e ? atoi(e) : 0;
-    }();
+static int bwd_cus() {
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess)
@@ -638,14 +685,52 @@ int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream) {
                                         dev);
         return n;
     }();
+    return cus;
+}
+
+// Narrow (32-column) tiles with a third LDS stage when the wide ones would
+// give each CU at most one block: the per-block MFMA time halves and two
+// blocks share a CU (measured 29.4 -> 28.7 ms per training step at batch
+// 512).  PCM_BWD_TILE=32|64 forces a width.
+static bool bwd_narrow(const CellBwdArgs &a) {
+    static const int force = [] {
+        const char *e = getenv("PCM_BWD_TILE");
+        return e ? atoi(e) : 0;
+    }();
     const int nbt = (a.B + BCM - 1) / BCM;
-    const bool narrow = force ? force == 32 : (a.NT / 64) * nbt <= cus;
-    const int nct = a.NT / (narrow ? 32 : 64);
+    return force ? force == 32 : (a.NT / 64) * nbt <= bwd_cus();
+}
+
+// Number of K-part partials a layer-0 launch leaves its input-side gradient
+// in (1 = the plain result): the XPART variant, for narrow tiles whose
+// input-side columns divide the hidden-side column tiles evenly.
+int pcm_cell_bwd_xparts(const CellBwdArgs &a) {
+    static const bool on = [] {
+        const char *e = getenv("PCM_BWD_XPART");
+        return !e || atoi(e) != 0;
+    }();
+    const int kx = a.NT - a.H;
+    if (!on || !bwd_narrow(a) || a.gates_low || a.dx_accumulate || kx <= 0 ||
+        a.drop_p > 0.f || a.H % kx != 0)
+        return 1;
+    const int parts = a.H / kx;              // = (H/32) / (kx/32)
+    return (3 * a.H / BCK) % parts == 0 ? parts : 1;
+}
+
+int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream) {
+    const int nbt = (a.B + BCM - 1) / BCM;
+    const bool narrow = bwd_narrow(a);
     CellBwdArgs b = a;
+    b.xparts = pcm_cell_bwd_xparts(a);
+    const bool xpart = b.xparts > 1;
+    const int nct = (xpart ? a.H : a.NT) / (narrow ? 32 : 64);
     b.reg_cols = (nct + 3) / 4;
     b.reg_rows = (nbt + 1) / 2;
     dim3 grid(8 * b.reg_cols * b.reg_rows);
-    if (narrow)
+    if (xpart)
+        hipLaunchKernelGGL((gru_cell_bwd_kernel<32, 3, true>), grid, dim3(512), 0,
+                           stream, b);
+    else if (narrow)
         hipLaunchKernelGGL((gru_cell_bwd_kernel<32, 3>), grid, dim3(512), 0,
                            stream, b);
     else
