@@ -56,6 +56,51 @@ def test_size_helpers_without_gpu():
     assert lib.pcm_kl_scratch_floats(131072) == 128
 
 
+def test_argument_checks_reject_before_any_launch():
+    """Bad arguments come back as error codes with a message, before anything
+    is enqueued (so no device is needed to see them)."""
+    from paccmann_chemistry_amd import _lib
+    lib = _lib.load()
+    dims = _lib.make_dims(4, 20, 20, 32, 2, 7, 5, True)
+    buf = (ctypes.c_float * 64)()
+    somewhere = ctypes.cast(buf, ctypes.c_void_p)
+    weights = _lib.PcmStackGRUParams()
+    for name, _ in weights._fields_:
+        field = getattr(weights, name)
+        if hasattr(field, '__len__'):
+            for i in range(2):
+                field[i] = somewhere.value
+        else:
+            setattr(weights, name, somewhere.value)
+    need = lib.pcm_stackgru_saved_bytes(ctypes.byref(dims), 3, 0)
+
+    def forward(active, saved_bytes=need, dropout=0.0, lengths=somewhere):
+        act = None
+        if active is not None:
+            act = ctypes.cast((ctypes.c_int32 * 3)(*active), ctypes.c_void_p)
+        return lib.pcm_stackgru_forward(
+            ctypes.byref(dims), ctypes.byref(weights), somewhere, 3, lengths,
+            act, None, 0, None, dropout, 0, 0, somewhere, saved_bytes, None,
+            None, None, None)
+
+    assert forward([4, 2, 3]) != 0            # grows again at step 2
+    assert b'non-increasing' in lib.pcm_last_error()
+    assert forward([5, 2, 1]) != 0            # more rows than the batch
+    assert forward([4, 2, 1], lengths=None) != 0
+    assert b'needs lengths' in lib.pcm_last_error()
+    assert forward(None, saved_bytes=16) != 0
+    assert b'workspace' in lib.pcm_last_error()
+    assert forward(None, dropout=1.5) != 0
+    assert b'dropout' in lib.pcm_last_error()
+    assert lib.pcm_prepare_batch(None, None, 4, 3, 0, None, 1.0, 0, None, 1,
+                                 None, None, None, None) != 0
+    assert b'null pointer' in lib.pcm_last_error()
+    assert lib.pcm_prepare_batch(somewhere, somewhere, 4, 3, 1, None, 1.0, 0,
+                                 None, 1, somewhere, somewhere, somewhere,
+                                 None) != 0
+    assert b'step_base' in lib.pcm_last_error()
+
+
 PARAMS = {
     'latent_dim': 16, 'rnn_cell_size': 32, 'embedding_size': 20,
     'vocab_size': 20, 'stack_width': 5, 'stack_depth': 7, 'n_layers': 2,
