@@ -677,28 +677,18 @@ int pcm_launch_gate_bwd(const GateBwdArgs &a, hipStream_t stream) {
     return 0;
 }
 
-static int bwd_cus() {
-    static const int cus = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess)
-            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount,
-                                        dev);
-        return n;
-    }();
-    return cus;
-}
-
-// Narrow (32-column) tiles with a third LDS stage when the wide ones would
-// give each CU at most one block: the per-block MFMA time halves and two
-// blocks share a CU (measured 29.4 -> 28.7 ms per training step at batch
-// 512).  PCM_BWD_TILE=32|64 forces a width.
+// Narrow (32-column) tiles with a third LDS stage are the default: half the MFMA
+// time per block and two or more blocks per CU measured faster than the wide
+// (64-column, two-stage) variant at every batch tried (ms per training step,
+// wide -> narrow: batch 512 29.4 -> 28.7, 768 43.9 -> 40.0, 1024 49.5 -> 48.3,
+// 2048 88.3 -> 86.8).  PCM_BWD_TILE=64 selects the wide one.
 static bool bwd_narrow(const CellBwdArgs &a) {
     static const int force = [] {
         const char *e = getenv("PCM_BWD_TILE");
         return e ? atoi(e) : 0;
     }();
-    const int nbt = (a.B + BCM - 1) / BCM;
-    return force ? force == 32 : (a.NT / 64) * nbt <= bwd_cus();
+    (void)a;
+    return force != 64;
 }
 
 // Number of K-part partials a layer-0 launch leaves its input-side gradient

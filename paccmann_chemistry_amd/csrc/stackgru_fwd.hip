@@ -868,9 +868,14 @@ int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
         return n;
     }();
     const int nbt = (a.B + CM - 1) / CM;
-    // narrow tiles once the wide ones leave half of the CUs without a block
-    // (at exactly one wide block per CU the two run alike: 16.5 against 15.5 us)
-    const bool narrow = force ? force == 16 : 2 * (a.Hn / CN) * nbt <= cus;
+    // Narrow tiles when they balance better over the CUs: a wide block is two
+    // units of work, a narrow one 1.06 (measured: 16.5 against 15.5 us at one
+    // wide block per CU); compare the busiest CU's load.  Batch 512 -> wide
+    // (256 blocks), 768 -> narrow (43.4 -> 41.5 ms per step), <= 256 -> narrow.
+    const int wide_tiles = (a.Hn / CN) * nbt;
+    const float load_wide = 2.0f * ((wide_tiles + cus - 1) / cus);
+    const float load_narrow = 1.06f * ((2 * wide_tiles + cus - 1) / cus);
+    const bool narrow = force ? force == 16 : load_narrow < load_wide;
     if (narrow) {
         dim3 grid(a.Hn / NCN, nbt);
         hipLaunchKernelGGL(gru_cell_fwd16_kernel, grid, dim3(512), 0, stream, a);

@@ -768,3 +768,28 @@ def test_prepare_batch_on_device_bernoulli():
     with pytest.raises(RuntimeError):
         U.prepare_batch_on_device([torch.ones(3), torch.ones(5)], True,
                                   device=_dev())
+
+
+@pytest.mark.parametrize('env', [
+    {'PCM_BWD_TILE': '64', 'PCM_FWD_TILE': '32', 'PCM_STACK_LEAN': '0'},
+    {'PCM_FWD_TILE': '16', 'PCM_BWD_XPART': '0', 'PCM_STACK_LEAN': '1'},
+    {'PCM_FUSED_CHOOSE': '0'},
+])
+def test_alternate_kernel_variants(env):
+    """The launchers pick tile widths / kernel variants by shape; the variants
+    a given shape would not pick (wide reverse tiles, forced narrow / wide
+    forward tiles, lean or prefetching stack step, plain layer-0 reverse cell,
+    two-launch output layer + search) are forced through their environment
+    switches -- read once per process, hence a child process -- over the
+    config-shaped, packed and greedy-decode fixtures."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests',
+           'test_gpu_parity.py'), '-x', '-q', '-p', 'no:cacheprovider', '-k',
+           'vae_config_golden or vae_small_golden or greedy_decode']
+    res = subprocess.run(cmd, env=dict(os.environ, **env), cwd=ROOT,
+                         capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
+    assert ' passed' in res.stdout
