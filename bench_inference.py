@@ -90,7 +90,7 @@ def main():
             return vae.decoder.generate_from_latent(
                 z, prime, end, search=search,
                 generate_len=args.generate_len, seed=99)
-        sec = timed(run, max(2, args.batches // 2), warmup=3)
+        sec = timed(run, args.batches, warmup=3)
         print(json.dumps(dict(
             common, metric=f'decode molecules/sec ({name})',
             value=batch / sec, unit='molecules/s', ms_per_batch=sec * 1e3,

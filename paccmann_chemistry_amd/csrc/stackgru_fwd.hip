@@ -725,6 +725,134 @@ __global__ __launch_bounds__(STHREADS, LEAN ? 4 : 2) void stack_step_fwd_kernel(
     }
 }
 
+
+// Stack step for large batches: 16 batch rows per block.  The 3 + W control /
+// push pre-activations of the 16 rows are one [16 x H] . [H x 64] product on
+// 16x16x4 MFMAs (wave w: output column tile w & 3, K half w >> 2, operands
+// straight from L2 as in logits_choose_kernel), so the weights are read once
+// per 16 rows instead of once per row or two; the stack update then streams
+// S_prev -> S_new from global memory (the three taps of an element hit the same
+// lines in L1), with no LDS staging of the stacks and nothing but loads,
+// multiply-adds and stores on the way.
+constexpr int MROWS = 16;
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__global__ __launch_bounds__(512) void stack_step_fwd_mfma_kernel(StackFwdArgs a) {
+    __shared__ float part[2][MROWS][65];   // [K half][row][output]
+    __shared__ float cu[MROWS][64];        // a[3], v[W] per row
+    const int H = a.H, W = a.W, D = a.D, DW = D * W, NO = 3 + W;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b0 = blockIdx.x * MROWS;
+    {
+        const int r16 = lane & 15, g = lane >> 4;
+        const int ct = wave & 3, kh = wave >> 2;
+        const int o = min(ct * 16 + r16, NO - 1);
+        const float *wrow = (o < 3 ? a.ctrl_w + (long long)o * H
+                                   : a.push_w + (long long)(o - 3) * H) + 4 * g;
+        const float *hrow =
+            a.htop + (long long)min(b0 + r16, a.B - 1) * a.Hp + 4 * g;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int klen = H / 2, kend = (kh + 1) * klen;
+        int k = kh * klen;
+        for (; k + 128 <= kend; k += 128) {
+            f32x4 fa[8], fb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                fa[i] = *(const f32x4 *)(hrow + k + 16 * i);
+                fb[i] = *(const f32x4 *)(wrow + k + 16 * i);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[i][e],
+                                                               acc, 0, 0, 0);
+        }
+        for (; k < kend; k += 16) {
+            const f32x4 fa = *(const f32x4 *)(hrow + k);
+            const f32x4 fb = *(const f32x4 *)(wrow + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[e], acc, 0,
+                                                           0, 0);
+        }
+        // D[i][j]: lane holds rows i = 4 g + e, column j = r16
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[kh][4 * g + e][ct * 16 + r16] = acc[e];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < MROWS * 64; idx += 512) {
+        const int r = idx >> 6, o = idx & 63;
+        float v = 0.f;
+        if (o < NO) {
+            v = part[0][r][o] + part[1][r][o];
+            v += o < 3 ? a.ctrl_b[o] : a.push_b[o - 3];
+            if (o >= 3) v = tanhf(v);
+        }
+        cu[r][o] = v;
+    }
+    __syncthreads();
+    if (tid < MROWS) {
+        float *c = cu[tid];
+        const float m = fmaxf(c[0], fmaxf(c[1], c[2]));
+        const float e0 = expf(c[0] - m), e1 = expf(c[1] - m), e2 = expf(c[2] - m);
+        const float s = e0 + e1 + e2;
+        c[0] = e0 / s; c[1] = e1 / s; c[2] = e2 / s;
+    }
+    __syncthreads();
+    // record a, v (needed by the reverse pass)
+    for (int idx = tid; idx < MROWS * a.AVW; idx += 512) {
+        const int r = idx / a.AVW, o = idx - r * a.AVW;
+        if (b0 + r < a.B)
+            a.av[(long long)(b0 + r) * a.AVW + o] = o < NO ? cu[r][o] : 0.f;
+    }
+    // the update, four consecutive elements per thread (DW % 4 == 0)
+    const int nq = DW >> 2;
+    const float inv_nq = 1.0f / (float)nq, inv_W = 1.0f / (float)W;
+#pragma unroll 4
+    for (int idx = tid; idx < MROWS * nq; idx += 512) {
+        const int r = pcm_fdiv(idx, inv_nq), q = idx - r * nq;
+        const int b = b0 + r;
+        if (b >= a.B) continue;
+        const float *Sp = a.S_prev + (long long)b * DW;
+        const f32x4 sv = *(const f32x4 *)(Sp + q * 4);
+        f32x4 nv = sv;
+        if (!(a.lengths && a.t >= a.lengths[b])) {
+            const float *c = cu[r];
+            const int e0 = q * 4;
+            // rows above (d - 1; the pushed value for d == 0) and below (d + 1;
+            // zero under the last row): element-wise, a group of four may
+            // straddle a row boundary
+            f32x4u up4 = {0.f, 0.f, 0.f, 0.f}, dn4 = up4;
+            if (e0 >= W) up4 = *(const f32x4u *)(Sp + e0 - W);
+            if (e0 + 3 + W < DW) dn4 = *(const f32x4u *)(Sp + e0 + W);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = e0 + i;
+                const float up = e < W ? c[3 + e] : (e0 >= W ? up4[i] : Sp[e - W]);
+                const float dn = e + W >= DW ? 0.f
+                                 : (e0 + 3 + W < DW ? dn4[i] : Sp[e + W]);
+                // reference order: no_op*S, + push*up, + pop*down
+                nv[i] = __fadd_rn(__fadd_rn(__fmul_rn(c[2], sv[i]),
+                                            __fmul_rn(c[0], up)),
+                                  __fmul_rn(c[1], dn));
+            }
+        }
+        *(f32x4 *)(a.S_new + (long long)b * DW + q * 4) = nv;
+        float *xt = a.xtop + (long long)b * a.Wp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (q * 4 + i < W) xt[q * 4 + i] = nv[i];   // row 0 = the new top
+    }
+    const int padw = a.Wp - W;
+    for (int idx = tid; idx < MROWS * padw; idx += 512) {
+        const int r = idx / padw, w = W + idx - r * padw;
+        if (b0 + r < a.B) a.xtop[(long long)(b0 + r) * a.Wp + w] = 0.f;
+    }
+    (void)D; (void)inv_W;
+}
+
 // ------------------------------------------------------------------------------
 // weight packing, state init, copies
 // ------------------------------------------------------------------------------
@@ -903,6 +1031,18 @@ int pcm_launch_stack_fwd(const StackFwdArgs &a, hipStream_t stream) {
                                         dev);
         return n;
     }();
+    // large batches: 16 rows per block with the dot products on MFMA
+    static const int mfma_rows = [] {
+        const char *e = getenv("PCM_STACK_MFMA");   // rows from which it is used
+        return e ? atoi(e) : 4096;
+    }();
+    if (a.B >= mfma_rows && (a.H % 32) == 0 && (a.Hp % 4) == 0 &&
+        3 + a.W <= 64 && ((a.D * a.W) & 3) == 0 && a.AVW <= 64) {
+        hipLaunchKernelGGL(stack_step_fwd_mfma_kernel,
+                           dim3((a.B + MROWS - 1) / MROWS), dim3(512), 0, stream,
+                           a);
+        return 0;
+    }
     const int rows = a.B <= 2 * cus ? 1 : 2;
     const dim3 grid((a.B + rows - 1) / rows);
     const bool lean = force >= 0 ? force == 1 : (int)grid.x > cus;

@@ -773,12 +773,12 @@ def test_prepare_batch_on_device_bernoulli():
 @pytest.mark.parametrize('env', [
     {'PCM_BWD_TILE': '64', 'PCM_FWD_TILE': '32', 'PCM_STACK_LEAN': '0'},
     {'PCM_FWD_TILE': '16', 'PCM_BWD_XPART': '0', 'PCM_STACK_LEAN': '1'},
-    {'PCM_FUSED_CHOOSE': '0'},
+    {'PCM_FUSED_CHOOSE': '0', 'PCM_STACK_MFMA': '1'},
 ])
 def test_alternate_kernel_variants(env):
     """The launchers pick tile widths / kernel variants by shape; the variants
     a given shape would not pick (wide reverse tiles, forced narrow / wide
-    forward tiles, lean or prefetching stack step, plain layer-0 reverse cell,
+    forward tiles, lean / prefetching / MFMA stack step, plain layer-0 reverse cell,
     two-launch output layer + search) are forced through their environment
     switches -- read once per process, hence a child process -- over the
     config-shaped, packed and greedy-decode fixtures."""
