@@ -64,6 +64,25 @@ def get_data_preparation(mode):
     return MODES[mode]
 
 
+def save_checkpoint(path, model, optimizer, epoch, loss_tracker=None):
+    """Everything a resumed run needs (the reference saves the model's
+    state_dict only, vae.py:674-676 / training.py:208-213, and cannot resume):
+    model and optimizer state, the next epoch, the best-loss bookkeeping."""
+    torch.save({
+        'model': model.state_dict(), 'optimizer': optimizer.state_dict(),
+        'epoch': int(epoch), 'loss_tracker': loss_tracker
+    }, path)
+
+
+def load_checkpoint(path, model, optimizer=None):
+    """Restore what save_checkpoint wrote; returns (epoch, loss_tracker)."""
+    state = torch.load(path, map_location=get_device(), weights_only=True)
+    model.load_state_dict(state['model'])
+    if optimizer is not None:
+        optimizer.load_state_dict(state['optimizer'])
+    return state['epoch'], state['loss_tracker']
+
+
 def test_vae(model, dataloader, logger, input_keep, batch_mode):
     """training.py:20-67: average (loss, reconstruction, KL) over the data."""
     device = get_device()
@@ -122,10 +141,13 @@ def train_vae(
     kl_growth=0.0015, input_keep=1., test_input_keep=0., start_index=2,
     end_index=3, generate_len=100, log_interval=100, eval_interval=200,
     save_interval=200, loss_tracker=None, logger=None, batch_mode='padded',
-    writer=None
+    writer=None, persistent_optimizer=None
 ):  # yapf: disable
     """training.py:70-325: one epoch.  The optimizer is re-created at the top
-    of every epoch exactly as the reference does (training.py:132)."""
+    of every epoch exactly as the reference does (training.py:132), unless the
+    caller passes ``persistent_optimizer`` (not in the reference: an optimizer
+    instance that keeps its moments across epochs and can be checkpointed with
+    ``save_checkpoint`` for a resume)."""
     if loss_tracker is None:
         loss_tracker = {
             'test_loss_a': 10e4, 'test_rec_a': 10e4, 'test_kld_a': 10e4,
@@ -137,7 +159,10 @@ def train_vae(
     vae_model = model.to(device)
     vae_model.train()
     train_loss = 0
-    optimizer = OPTIMIZER_FACTORY[optimizer](vae_model.parameters(), lr=lr)
+    if persistent_optimizer is not None:
+        optimizer = persistent_optimizer
+    else:
+        optimizer = OPTIMIZER_FACTORY[optimizer](vae_model.parameters(), lr=lr)
     t = time()
     loss = decoder_loss = None
     for _iter, batch in enumerate(train_dataloader):

@@ -80,3 +80,54 @@ def test_train_vae_epochs(tmp_path, batch_mode):
     again = P.TeacherVAE(P.StackGRUEncoder(params), P.StackGRUDecoder(params))
     again.load(str(best))
     assert (tmp_path / 'weights' / 'saved_model_epoch_0_iter_6.pt').exists()
+
+
+def test_resume_reproduces_uninterrupted_run(tmp_path):
+    """Two epochs with a persistent optimizer == one epoch, save_checkpoint,
+    load_checkpoint into fresh objects, one more epoch: same weights bit for
+    bit (dropout 0, no word dropout, fixed batch order)."""
+    import paccmann_chemistry_amd as P
+    from paccmann_chemistry_amd.training import (
+        load_checkpoint, save_checkpoint, train_vae
+    )
+    from paccmann_chemistry_amd.utils import collate_fn
+    params = {
+        'latent_dim': 16, 'rnn_cell_size': 64, 'embedding_size': 24,
+        'vocab_size': 24, 'stack_width': 8, 'stack_depth': 10, 'n_layers': 2,
+        'dropout': 0.0, 'batch_size': 32, 'batch_mode': 'padded',
+        'embedding': 'one_hot', 'use_stack': True, 'bidirectional': False
+    }
+    loader = torch.utils.data.DataLoader(
+        _dataset(128, 24, 5), batch_size=32, shuffle=False, drop_last=True,
+        collate_fn=collate_fn)
+    os.makedirs(tmp_path / 'weights')
+    logger = logging.getLogger('test_train_loop')
+    kw = dict(search=P.GreedySearch(), lr=5e-3, kl_growth=0.003, input_keep=1.,
+              log_interval=10 ** 9, eval_interval=10 ** 9,
+              save_interval=10 ** 9, logger=logger, batch_mode='padded')
+
+    def fresh():
+        torch.manual_seed(11)
+        vae = P.TeacherVAE(P.StackGRUEncoder(params),
+                           P.StackGRUDecoder(params)).to('cuda')
+        return vae, torch.optim.Adam(vae.parameters(), lr=5e-3)
+
+    def epoch(vae, opt, e):
+        torch.manual_seed(100 + e)      # the reparameterisation draws
+        train_vae(e, vae, loader, loader, _Language(), str(tmp_path),
+                  persistent_optimizer=opt, **kw)
+
+    vae, opt = fresh()
+    epoch(vae, opt, 0)
+    epoch(vae, opt, 1)
+    straight = {k: v.clone() for k, v in vae.state_dict().items()}
+
+    vae, opt = fresh()
+    epoch(vae, opt, 0)
+    save_checkpoint(str(tmp_path / 'ckpt.pt'), vae, opt, 1, {'ep_loss': 0})
+    vae, opt = fresh()
+    nxt, tracker = load_checkpoint(str(tmp_path / 'ckpt.pt'), vae, opt)
+    assert nxt == 1 and tracker == {'ep_loss': 0}
+    epoch(vae, opt, nxt)
+    for key, val in vae.state_dict().items():
+        assert torch.equal(val, straight[key]), key
