@@ -49,7 +49,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=PARAMS['batch_size'],
                     help='sequences per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=128)
+    ap.add_argument('--cpu-batch', type=int, default=512)
     ap.add_argument('--ragged', action='store_true',
                     help='secondary workload: packed mode on ragged lengths '
                          '~N(60,20) clipped to [10,120] (tokens/s counts the '
