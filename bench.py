@@ -94,6 +94,7 @@ def cpu_baseline(p, cpu_batch):
     autograd + torch.optim.Adam as training.py:132-156) on a bounded sample."""
     from oracle import stackgru_oracle as O
     from oracle import weights as W
+    O.ATEN_CELL = True   # the layer-step on ATen's GRU cell, as nn.GRU runs it
     threads = torch.get_num_threads()
     q = dict(p, batch_size=cpu_batch, dropout=0.0)
     sd = W.make_state_dict(q, 1234)

@@ -87,8 +87,18 @@ def stack_augmentation(push_val, prev_stack, controls):
     return new_stack
 
 
+# True: one layer-step runs ATen's own GRU cell (torch.gru_cell, the kernel
+# behind the reference's nn.GRU call on CPU) instead of the gate-by-gate
+# restatement below.  Same numbers to rounding (tests/test_oracle_golden.py);
+# bench.py's cpu_baseline switches it on so that the timed oracle costs what the
+# reference costs (oracle/time_vs_reference.py), the parity tests leave it off.
+ATEN_CELL = False
+
+
 def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
     """One layer, one time step of torch.nn.GRU (gate order r, z, n)."""
+    if ATEN_CELL:
+        return torch.gru_cell(x, h, w_ih, w_hh, b_ih, b_hh)
     hid = h.shape[1]
     gi = x @ w_ih.t() + b_ih
     gh = h @ w_hh.t() + b_hh

@@ -171,3 +171,21 @@ def test_batch_independence_invariant():
             _close(row, mu[0], rtol=1e-5, atol=1e-7)
     for other in results[1:]:
         _close(other, results[0], rtol=1e-5, atol=1e-7)
+
+
+def test_aten_cell_switch_matches_restatement():
+    """ATEN_CELL (what bench.py's cpu_baseline times) changes the kernel of
+    the layer-step, not the numbers."""
+    from oracle import stackgru_oracle as O
+    gen = torch.Generator().manual_seed(3)
+    x, h = torch.randn(7, 13, generator=gen), torch.randn(7, 24, generator=gen)
+    w_ih, w_hh = (torch.randn(72, 13, generator=gen),
+                  torch.randn(72, 24, generator=gen))
+    b_ih, b_hh = torch.randn(72, generator=gen), torch.randn(72, generator=gen)
+    plain = O.gru_cell(x, h, w_ih, w_hh, b_ih, b_hh)
+    O.ATEN_CELL = True
+    try:
+        aten = O.gru_cell(x, h, w_ih, w_hh, b_ih, b_hh)
+    finally:
+        O.ATEN_CELL = False
+    assert torch.allclose(plain, aten, rtol=1e-5, atol=1e-6)
