@@ -54,6 +54,17 @@ int main(int argc, char **argv) {
     }
     hipDeviceSynchronize();
     const double inter = ms(now() - t0);
+    // the same single chain replayed from a hipGraph
+    hipGraph_t graph; hipGraphExec_t exec;
+    hipStreamBeginCapture(a, hipStreamCaptureModeGlobal);
+    chain(a, x, blocks, n, cycles);
+    hipStreamEndCapture(a, &graph);
+    hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphLaunch(exec, a); hipStreamSynchronize(a);
+    t0 = now();
+    hipGraphLaunch(exec, a); hipStreamSynchronize(a);
+    const double gr = ms(now() - t0);
+    printf("one chain as a hipGraph: %.2f ms (%.2f us/launch)\n", gr, gr * 1e3 / n);
     printf("blocks %d, %.1f us kernels, %d per chain: one chain %.2f ms (%.2f us/launch); "
            "two chains, two host threads %.2f ms; interleaved from one thread %.2f ms\n",
            blocks, us, n, one, one * 1e3 / n, two, inter);
