@@ -510,14 +510,28 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
             else if (extra) glds4(base, offx, dst);
             else glds4(base, off, dst);
         };
+        if constexpr (BNSTAGE >= 3) {
+            // One barrier per chunk: at barrier k every consumer has waited
+            // for its fragment reads of chunk k - 1 (lgkmcnt(0) in front of the
+            // barrier), so that chunk's stage is free for chunk k + 2 while
+            // chunk k is read and chunk k + 1 is in flight.
+            issue(0); issue(1);
+            for (int k = 0; k < ntot; ++k) {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+                raw_barrier();   // chunk k landed, stage of chunk k - 1 free
+                issue(k + 2);
+            }
+        } else {
 #pragma unroll
-        for (int c = 0; c < BNSTAGE; ++c) issue(c);
-        for (int k = 0; k < ntot; ++k) {
-            // chunk k landed (the newest BNSTAGE - 1 chunks may be in flight)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (BNSTAGE - 1)) : "memory");
-            raw_barrier();   // A_k: the consumers may read chunk k
-            raw_barrier();   // B_k: they hold its fragments, the stage is free
-            issue(k + BNSTAGE);
+            for (int c = 0; c < BNSTAGE; ++c) issue(c);
+            for (int k = 0; k < ntot; ++k) {
+                // chunk k landed (the newest chunk may be in flight)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI * (BNSTAGE - 1))
+                             : "memory");
+                raw_barrier();   // A_k: the consumers may read chunk k
+                raw_barrier();   // B_k: they hold its fragments, the stage is free
+                issue(k + BNSTAGE);
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
@@ -542,7 +556,8 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
                 if constexpr (BCN == 64)
                     f1[s] = *(const f32x4 *)(As + (BCM + 32) * BCK + slot[s]);
             }
-            raw_barrier();   // B_c (waits for the fragment reads first)
+            if constexpr (BNSTAGE < 3)
+                raw_barrier();   // B_c (waits for the fragment reads first)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
