@@ -596,6 +596,61 @@ __global__ __launch_bounds__(STHREADS, LEAN ? 4 : 2) void stack_step_fwd_kernel(
                 }
             }
         }
+    } else if (LEAN && (H & 255) == 0 && H <= 1024 && NO <= 8 * SOUT) {
+        // 16-byte loads, four consecutive k per lane: a quarter of the load
+        // instructions of the lane-strided loop below, all in flight at once
+        // (the dot products are what this kernel spends most time in: every
+        // block streams the whole [Wc ; Ws] from L2)
+        float p[SOUT][SROWS];
+        const float *wrow[SOUT];
+#pragma unroll
+        for (int i = 0; i < SOUT; ++i) {
+            const int o = min(wave * SOUT + i, NO - 1);
+            wrow[i] = (o < 3 ? a.ctrl_w + (long long)o * H
+                             : a.push_w + (long long)(o - 3) * H) + 4 * lane;
+#pragma unroll
+            for (int r = 0; r < SROWS; ++r) p[i][r] = 0.f;
+        }
+#pragma unroll
+        for (int k0 = 0; k0 < 1024; k0 += 256) {
+            if (k0 < H) {
+                f32x4 w[SOUT];
+#pragma unroll
+                for (int i = 0; i < SOUT; ++i)
+                    w[i] = *(const f32x4 *)(wrow[i] + k0);
+#pragma unroll
+                for (int r = 0; r < SROWS; ++r) {
+                    const f32x4 hv =
+                        *(const f32x4 *)(hrow + r * H + k0 + 4 * lane);
+#pragma unroll
+                    for (int i = 0; i < SOUT; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            p[i][r] = fmaf(w[i][e], hv[e], p[i][r]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < SOUT; ++i)
+#pragma unroll
+            for (int r = 0; r < SROWS; ++r) {
+                float v = p[i][r];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                p[i][r] = v;
+            }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < SOUT; ++i) {
+                const int o = wave * SOUT + i;
+                if (o < NO) {
+                    const float bias = o < 3 ? a.ctrl_b[o] : a.push_b[o - 3];
+#pragma unroll
+                    for (int r = 0; r < SROWS; ++r)
+                        cu[r * a.AVW + o] = p[i][r] + bias;
+                }
+            }
+        }
     } else
     for (int obase = wave * SOUT; obase < NO; obase += 8 * SOUT) {
         float p[SOUT][SROWS];
