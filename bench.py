@@ -7,14 +7,19 @@ batches -- BASELINE.json configs[1]: batch 512 per GPU, seq len 120, vocab 60
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Rank 0 prints ONE JSON line (see the field notes in DESIGN.md section
-"Measurement").  `roofline` is for the dominant kernel (by summed time: the
-fused GRU cell of the reverse recurrence, `--probe 5`; `--probe 1` is the
-forward cell), its duration measured live with HIP events on the launch stream
-during the timed steps; `roofline.traffic` is the HBM-side byte count per launch
-from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json), not a live
-measurement; `cpu_baseline` times the CPU oracle (oracle/stackgru_oracle.py,
-kind "port") on a bounded sample on rank 0.
+Rank 0 prints ONE JSON line (field notes in DESIGN.md section "Measurement").
+`value` comes from the timed steps, which carry no instrumentation.  After
+them, one extra untimed step per kernel family is run with that family's
+launches made through hipExtLaunchKernelGGL with a (start, stop) event pair
+bound to each kernel's own dispatch (`pcm_probe_enable`): the per-launch
+durations are the kernels' begin -> end on the device, the interval a rocprofv3
+kernel trace reports.  `roofline` is the family with the largest summed time,
+`roofline_kernels` lists every family, `step_roofline` prices the whole step
+(tokens/s x 29.8 MFLOP against the fp32 MFMA peak).
+`roofline.traffic` is the memory-side byte count per launch from the committed
+rocprofv3 PMC passes (profiles/pmc_traffic.json), not a live measurement;
+`cpu_baseline` times the CPU oracle (oracle/stackgru_oracle.py, kind "port") on
+a bounded sample on rank 0.
 """
 import argparse
 import ctypes
@@ -55,26 +60,48 @@ def parse():
                          '~N(60,20) clipped to [10,120] (tokens/s counts the '
                          'real tokens); the default is the fixed-length '
                          'padded batch BASELINE.json names')
-    ap.add_argument('--probe', type=int, default=5,
-                    help='kernel id for the roofline probe (5 = reverse fused '
-                         'cell, 1 = forward fused cell, 0 = off)')
+    ap.add_argument('--probe', type=int, default=1,
+                    help='1: per-kernel launch durations from extra untimed '
+                         'steps after the timed region (roofline); 0: off')
     args = ap.parse_args()
     if args.ragged:
         args.probe = 0   # per-launch FLOPs vary with the active row count
     return args
 
 
-def cell_flops_per_launch(p, batch):
-    """Algorithmic FLOPs of one fused-cell launch, averaged over the layers
-    (2*3H*(W+H) layer 0, 2*3H*2H further layers, per
-    sequence-step; the one-hot token part is a gather, 0 FLOP)."""
-    hid, width, layers = p['rnn_cell_size'], p['stack_width'], p['n_layers']
-    per_seq = [2 * 3 * hid * (width + hid)] + \
-        [2 * 3 * hid * 2 * hid] * (layers - 1)
-    return batch * sum(per_seq) / layers
+PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md, HBM3E
 
 
-PROBE_KERNELS = {1: 'gru_cell_fwd_kernel', 5: 'gru_cell_bwd_kernel'}
+def probe_families(p, batch, seq_len):
+    """(probe id, kernel, bound, algorithmic work per launch) of the kernels of
+    the recurrence and the weight-gradient GEMM.  FLOPs / bytes per
+    sequence-step as SURVEY.md section 8d counts them (the one-hot token part is
+    a gather, 0 FLOP; the stack moves 2*D*W*4 bytes forward and 3*D*W*4 in the
+    reverse pass, whose launch also carries the top layer's gate gradient:
+    9 reads / writes of H floats)."""
+    hid, width, depth = p['rnn_cell_size'], p['stack_width'], p['stack_depth']
+    layers = p['n_layers']
+    l0 = 2 * 3 * hid * (width + hid) * batch
+    l1 = 2 * 3 * hid * 2 * hid * batch
+    stack_fwd = 2 * depth * width * 4 * batch
+    stack_bwd = (3 * depth * width * 4 + 9 * hid * 4) * batch
+    # weight gradients of one StackGRU, the square-ish products that go
+    # through the wide K-major GEMM launches: dW_hh of every layer and dW_ih of
+    # layers >= 1 (the skinny stack-top / control / token products are separate,
+    # narrow launches and are not priced here)
+    dw = (2 * 3 * hid * hid + (layers - 1) * 2 * 3 * hid * 2 * hid) \
+        * batch * seq_len
+    fams = [
+        (11, 'gru_cell_fwd_kernel (layer 0)', 'mfma', l0),
+        (2, 'stack_step_fwd_kernel', 'hbm', stack_fwd),
+        (51, 'gru_cell_bwd_kernel (layer 0)', 'mfma', l0),
+        (4, 'stack_bwd_kernel (+ top-layer gate gradient)', 'hbm', stack_bwd),
+        (6, 'gemm_tn_kernel<0> (dW_hh, dW_ih of one StackGRU)', 'mfma', dw),
+    ]
+    if layers > 1:
+        fams.insert(1, (12, 'gru_cell_fwd_kernel (layers >= 1)', 'mfma', l1))
+        fams.insert(4, (52, 'gru_cell_bwd_kernel (layers >= 1)', 'mfma', l1))
+    return fams
 
 
 def pmc_traffic(kernel):
@@ -84,7 +111,8 @@ def pmc_traffic(kernel):
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         with open(path) as f:
-            return json.load(f)['kernels'][kernel]['bytes_per_launch']
+            return json.load(f)['kernels'][kernel.split(' ')[0]][
+                'bytes_per_launch']
     except (OSError, KeyError, ValueError):
         return None
 
@@ -93,7 +121,7 @@ def cpu_baseline(p, cpu_batch):
     """The oracle (CPU restatement of the reference, torch CPU kernels +
     autograd + torch.optim.Adam as training.py:132-156) on a bounded sample."""
     from oracle import stackgru_oracle as O
-    from oracle import weights as W
+    from paccmann_chemistry_amd import synthetic as W
     O.ATEN_CELL = True   # the layer-step on ATen's GRU cell, as nn.GRU runs it
     threads = torch.get_num_threads()
     q = dict(p, batch_size=cpu_batch, dropout=0.0)
@@ -105,7 +133,8 @@ def cpu_baseline(p, cpu_batch):
     targets = W.shifted_targets(tokens)
     gen = torch.Generator().manual_seed(7)
     times = []
-    for it in range(3):
+    warm, timed = 2, 3   # 2 warm-ups, median of >= 3
+    for it in range(warm + timed):
         eps = torch.randn(cpu_batch, q['latent_dim'], generator=gen)
         t0 = time.perf_counter()
         opt.zero_grad()
@@ -116,15 +145,16 @@ def cpu_baseline(p, cpu_batch):
         loss.backward()
         opt.step()
         times.append(time.perf_counter() - t0)
-    best = min(times[1:])
+    median = sorted(times[warm:])[timed // 2]
     return {
-        'value': cpu_batch * SEQ_LEN / best,
+        'value': cpu_batch * SEQ_LEN / median,
         'unit': 'tokens/s',
         'cores': threads,
         'kind': 'port',
         'sample': f'oracle train step (fwd+bwd+Adam), batch {cpu_batch} x '
-                  f'seq {SEQ_LEN}, 1 warm-up + best of 2 timed steps, '
-                  f'{threads} torch threads',
+                  f'seq {SEQ_LEN}, {warm} warm-ups + median of {timed} timed '
+                  f'steps, {threads} torch threads',
+        'step_seconds': [round(t, 3) for t in times],
     }
 
 
@@ -152,7 +182,7 @@ def main():
     from paccmann_chemistry_amd import _lib, dp
     from paccmann_chemistry_amd.ops import KLDivFn
     from paccmann_chemistry_amd.utils import kl_weight
-    from oracle import weights as W  # synthetic inputs only
+    from paccmann_chemistry_amd import synthetic as W
 
     p = dict(PARAMS, batch_size=args.batch)
     if args.ragged:
@@ -210,39 +240,37 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    cells_per_step = 2 * SEQ_LEN * p['n_layers']
-    if args.probe:
-        # the event brackets cost ~8 % when every launch carries them, so
-        # only the launches of the FIRST timed step are bracketed (the probe
-        # stops recording once its event budget is used)
-        _lib.check(lib.pcm_probe_enable(args.probe, cells_per_step), 'probe')
-    barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
     vae.check_tokens()
-    probe_ms, probe_n, dropped = (ctypes.c_double(), ctypes.c_int64(),
-                                  ctypes.c_int64())
-    if args.probe:
-        lib.pcm_probe_read(ctypes.byref(probe_ms), ctypes.byref(probe_n),
-                           ctypes.byref(dropped))
-        lib.pcm_probe_enable(0, 0)
+    final_loss = float(loss.item())
+    # per-kernel launch durations: one extra untimed step per kernel family
+    # (every rank runs the step, rank 0 records)
+    probed = []
+    if args.probe and not args.ragged:
+        probe_ms, probe_n, dropped = (ctypes.c_double(), ctypes.c_int64(),
+                                      ctypes.c_int64())
+        for k, (pid, name, bound, work) in enumerate(
+                probe_families(p, args.batch, SEQ_LEN)):
+            if rank == 0:
+                _lib.check(lib.pcm_probe_enable(pid, 4 * SEQ_LEN), 'probe')
+            step(args.warmup + args.steps + k)
+            torch.cuda.synchronize()
+            if rank == 0:
+                lib.pcm_probe_read(ctypes.byref(probe_ms),
+                                   ctypes.byref(probe_n),
+                                   ctypes.byref(dropped))
+                lib.pcm_probe_enable(0, 0)
+                probed.append((name, bound, work, probe_ms.value,
+                               probe_n.value))
+        barrier()
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    final_loss = float(loss.item())
-    # what an empty HIP-event bracket reads on this stream (marker cost that
-    # every probed duration carries on top of the kernel itself)
-    pairs = [(torch.cuda.Event(enable_timing=True),
-              torch.cuda.Event(enable_timing=True)) for _ in range(200)]
-    for e0, e1 in pairs:
-        e0.record()
-        e1.record()
-    torch.cuda.synchronize()
-    empty_us = sum(e0.elapsed_time(e1) for e0, e1 in pairs) / len(pairs) * 1e3
     assert final_loss == final_loss, 'loss is NaN'
 
     if rank == 0:
@@ -250,24 +278,41 @@ def main():
         # length distributions are the same)
         tokens_per_step = world * tokens_per_batch
         value = tokens_per_step * args.steps / elapsed
+        entries = []
+        for name, bound, work, total_ms, launches in probed:
+            if launches <= 0:
+                continue
+            avg_s = total_ms / launches * 1e-3
+            if name.startswith('gemm_tn'):
+                # the family's launches differ in size: price them together
+                # (two StackGRUs' worth of launches in one step)
+                achieved = 2 * work / (total_ms * 1e-3) / 1e12
+            elif bound == 'mfma':
+                achieved = work / avg_s / 1e12
+            else:
+                achieved = work / avg_s / 1e9
+            peak = PEAK_FP32_MFMA_TFLOPS if bound == 'mfma' else PEAK_HBM_GBS
+            entries.append({
+                'bound': bound, 'kernel': name, 'achieved': achieved,
+                'peak': peak, 'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
+                'frac': achieved / peak, 'traffic': pmc_traffic(name),
+                'avg_launch_us': avg_s * 1e6, 'launches': launches,
+                'ms_per_step': total_ms,
+            })
         roofline = None
-        if args.probe in PROBE_KERNELS and probe_n.value > 0:
-            # a bracket reads the kernel plus the cost of its two event
-            # markers; the empty bracket measured above is taken off so the
-            # figure is the launch duration rocprofv3 reports
-            raw_s = probe_ms.value / probe_n.value * 1e-3
-            avg_s = max(raw_s - empty_us * 1e-6, 1e-9)
-            achieved = cell_flops_per_launch(p, args.batch) / avg_s / 1e12
-            roofline = {
-                'bound': 'mfma', 'kernel': PROBE_KERNELS[args.probe],
-                'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
-                'traffic': pmc_traffic(PROBE_KERNELS[args.probe]),
-                'avg_launch_us': avg_s * 1e6, 'launches': probe_n.value,
-                'bracket_us': raw_s * 1e6, 'empty_bracket_us': empty_us,
-                'sample': 'HIP-event brackets on every launch of the first '
-                          'timed step, minus the empty-bracket reading',
-            }
+        if entries:
+            roofline = dict(max(entries, key=lambda e: e['ms_per_step']))
+            roofline['sample'] = (
+                'kernel begin -> end from the events hipExtLaunchKernelGGL '
+                'binds to each dispatch, every launch of one untimed step '
+                'after the timed region')
+        step_tflops = value * 29.8e6 / 1e12
+        step_roofline = {
+            'bound': 'mfma', 'achieved': step_tflops,
+            'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': step_tflops / PEAK_FP32_MFMA_TFLOPS,
+            'note': 'whole step: tokens/s x 29.8 MFLOP per token (SURVEY 8d)',
+        }
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(p, args.cpu_batch)
@@ -288,7 +333,8 @@ def main():
                 'global_batch': world * args.batch, 'seq_len': SEQ_LEN,
                 'parallelism': f'dp{world}',
             },
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': roofline, 'roofline_kernels': entries,
+            'step_roofline': step_roofline, 'cpu_baseline': cpu,
             'final_loss': final_loss,
         }
         print(json.dumps(line), flush=True)

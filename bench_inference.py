@@ -39,7 +39,7 @@ def main():
     ap.add_argument('--generate-len', type=int, default=100)
     args = ap.parse_args()
     import paccmann_chemistry_amd as P
-    from oracle import weights as W  # synthetic inputs only
+    from paccmann_chemistry_amd import synthetic as W
     dev = torch.device('cuda:0')
     torch.cuda.set_device(dev)
     p = dict(bench.PARAMS, batch_size=args.batch)

@@ -33,7 +33,7 @@ def main():
     ap.add_argument('--batches', type=int, default=24)
     args = ap.parse_args()
     import paccmann_chemistry_amd as P
-    from oracle import weights as W  # synthetic inputs only
+    from paccmann_chemistry_amd import synthetic as W
     from paccmann_chemistry_amd.training import train_vae
     from paccmann_chemistry_amd.utils import collate_fn
     logger = logging.getLogger('bench_train_loop')

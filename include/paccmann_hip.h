@@ -78,14 +78,17 @@ int pcm_device_check(void);
 
 /*
  * Measurement aid (no counterpart in the reference): while enabled for one
- * kernel id, each launch of that kernel inside the recurrence is bracketed by
- * hipEvents on its own stream.  pcm_probe_read synchronises on the recorded
- * events and returns the summed duration and launch count since enable.
- * Ids: 1 fused GRU cell (forward), 2 stack step (forward), 3 gate gradient,
- * 4 stack step (backward), 5 fused reverse GRU cell (the dgates.W products of
- * one layer-step; the generic GEMM group and its split-K reduce when the hidden
- * size is not a multiple of 64); 0 disables.  Not thread safe; one device per
- * process.
+ * kernel id, each launch of that kernel is made with a (start, stop) event
+ * pair bound to the kernel's own dispatch (hipExtLaunchKernelGGL), so the
+ * elapsed time is the kernel's begin -> end on the device -- the interval a
+ * rocprofv3 kernel trace reports -- and no marker packet joins the stream.
+ * pcm_probe_read synchronises on the recorded events and returns the summed
+ * duration and launch count since enable.
+ * Ids: 1 fused GRU cell, forward (11: layer 0 only, 12: layers >= 1 only);
+ * 2 stack step, forward; 3 gate gradient; 4 stack step, backward (with the top
+ * layer's fused gate gradient); 5 fused reverse GRU cell (51 / 52 as above);
+ * 6 wide K-major weight-gradient GEMM launches (dW_hh, dW_ih); 0 disables.  At most max_launches
+ * launches are recorded.  Not thread safe; one device per process.
  */
 int pcm_probe_enable(int32_t kernel_id, int32_t max_launches);
 int pcm_probe_read(double *total_ms, int64_t *launches, int64_t *dropped);
@@ -213,13 +216,20 @@ int pcm_linear_backward(const float *x, int64_t ldx, const float *w,
  *   targets  int64[T,B]
  *   lengths  int32[B] or NULL: step t averages over the rows with
  *            lengths[b] > t (all B rows when NULL; no ignore_index)
+ *   step_weight fp32[T] or NULL: when given, step t's row losses are scaled by
+ *            step_weight[t] INSTEAD of 1 / (rows active at step t).  Data
+ *            parallel training passes 1 / (rows active at step t over ALL
+ *            ranks), so that the sum of the ranks' losses is the single-process
+ *            loss of the global batch (vae.py:386 averages over the rows that
+ *            are active in the whole batch).
  *   loss     fp32[1]
  *   argmax   int64[B,T] (nullable) first maximum on ties; 0 where inactive
  *   dlogits  fp32[T,B,V] (nullable) d loss / d logits
- *   scratch  fp32[T*B + T] row losses and per-step 1/count (required)
+ *   scratch  fp32[T*B + T] row losses and per-step weights (required)
  */
 int pcm_softmax_ce(const float *logits, const int64_t *targets,
-                   const int32_t *lengths, int32_t steps, int32_t batch,
+                   const int32_t *lengths, const float *step_weight,
+                   int32_t steps, int32_t batch,
                    int32_t vocab, float *loss, int64_t *argmax, float *dlogits,
                    float *scratch, int32_t *status, void *stream);
 

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpaccmann_hip.so')
 PCM_MAX_LAYERS = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 SEARCH_GREEDY = 0
 SEARCH_SAMPLING = 1
@@ -88,7 +88,7 @@ PROTOTYPES = {
     ),
     'pcm_softmax_ce': (
         ctypes.c_int,
-        [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP]
+        [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP]
     ),
     'pcm_reparam_forward': (ctypes.c_int, [_VP, _VP, _VP, _VP, _I64, _VP]),
     'pcm_reparam_backward': (

@@ -44,7 +44,8 @@ int pcm_check_launch(const char *what) {
 // ---- launch-duration probe ----------------------------------------------------------
 #include <vector>
 int g_pcm_probe_id = 0;
-static std::vector<hipEvent_t> g_probe_ev;   // pairs: begin, end
+hipEvent_t g_pcm_probe_start = nullptr, g_pcm_probe_stop = nullptr;
+static std::vector<hipEvent_t> g_probe_ev;   // pairs: start, stop
 static size_t g_probe_used = 0;              // events handed out
 static size_t g_probe_cap = 0;
 static double g_probe_ms = 0.0;
@@ -61,19 +62,19 @@ static void probe_drain() {
             g_probe_n += 1;
         }
     }
+    (void)hipGetLastError();   // an unrecorded pair is not a failed call
     g_probe_used = 0;
 }
 
-void pcm_probe_begin_(int id, hipStream_t st) {
-    (void)id;
+void pcm_probe_begin_(void) {
     if (g_probe_used + 2 > g_probe_cap) { g_probe_dropped++; return; }
-    (void)hipEventRecord(g_probe_ev[g_probe_used], st);
+    g_pcm_probe_start = g_probe_ev[g_probe_used];
+    g_pcm_probe_stop = g_probe_ev[g_probe_used + 1];
 }
 
-void pcm_probe_end_(int id, hipStream_t st) {
-    (void)id;
-    if (g_probe_used + 2 > g_probe_cap) return;
-    (void)hipEventRecord(g_probe_ev[g_probe_used + 1], st);
+void pcm_probe_end_(void) {
+    if (!g_pcm_probe_start) return;
+    g_pcm_probe_start = g_pcm_probe_stop = nullptr;
     g_probe_used += 2;
 }
 
@@ -250,9 +251,9 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         s.av = sb.av; s.xtop = sb.xtop; s.lengths = lengths;
         s.B = Bt; s.H = lay.H; s.Hp = lay.Hp; s.D = lay.D; s.W = lay.W;
         s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
-        pcm_probe_begin(PCM_K_STACK_FWD, st);
+        pcm_probe_begin(PCM_K_STACK_FWD);
         int rc = pcm_launch_stack_fwd(s, st);
-        pcm_probe_end(PCM_K_STACK_FWD, st);
+        pcm_probe_end(PCM_K_STACK_FWD);
         if (rc) return rc;
     }
     for (int l = 0; l < lay.L; ++l) {
@@ -273,9 +274,9 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         c.t = t; c.next_layer = l + 1;
         c.drop_p = drop_p; c.inv_keep = drop_p < 1.f ? 1.f / (1.f - drop_p) : 0.f;
         c.seed = seed;
-        pcm_probe_begin(PCM_K_CELL_FWD, st);
+        pcm_probe_begin(PCM_K_CELL_FWD, l);
         int rc = pcm_launch_cell_fwd(c, st);
-        pcm_probe_end(PCM_K_CELL_FWD, st);
+        pcm_probe_end(PCM_K_CELL_FWD, l);
         if (rc) return rc;
     }
     return PCM_OK;
@@ -340,11 +341,13 @@ static int check_active_rows(const int32_t *active_rows, const int32_t *lengths,
 
 extern "C" {
 
-int pcm_version(void) { return 2; }
+int pcm_version(void) { return 3; }
 
 int pcm_probe_enable(int32_t kernel_id, int32_t max_launches) {
-    PCM_REQUIRE(kernel_id >= 0 && kernel_id <= PCM_K_GEMM, PCM_EINVAL,
-                "probe: unknown kernel id %d", kernel_id);
+    PCM_REQUIRE((kernel_id >= 0 && kernel_id <= PCM_K_DW_GEMM) ||
+                    kernel_id == 11 || kernel_id == 12 || kernel_id == 51 ||
+                    kernel_id == 52,
+                PCM_EINVAL, "probe: unknown kernel id %d", kernel_id);
     probe_drain();
     g_probe_ms = 0.0; g_probe_n = 0; g_probe_dropped = 0;
     if (kernel_id != 0) {
@@ -441,6 +444,13 @@ int pcm_stackgru_forward(const pcm_dims *dims,
     rc = check_active_rows(active_rows, lengths, steps, lay.B,
                            "stackgru_forward");
     if (rc) return rc;
+    if (lay.use_stack) {
+        // an unsupported stack size fails here, before any launch -- for a
+        // training-mode forward also against the reverse pass's (tighter) limit
+        rc = pcm_stack_fwd_check(lay.D, lay.W, lay.H, lay.AVW);
+        if (!rc && training) rc = pcm_stack_bwd_check(lay.D, lay.W, lay.AVW);
+        if (rc) return rc;
+    }
     const bool drop = training && dropout_p > 0.f && lay.L > 1;
     lay.dropout = drop ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
@@ -565,6 +575,10 @@ int pcm_stackgru_backward(const pcm_dims *dims,
     rc = check_active_rows(active_rows, lengths, steps, lay.B,
                            "stackgru_backward");
     if (rc) return rc;
+    if (lay.use_stack) {
+        rc = pcm_stack_bwd_check(lay.D, lay.W, lay.AVW);
+        if (rc) return rc;
+    }
     const bool drop = dropout_p > 0.f && lay.L > 1;
     lay.dropout = drop ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
@@ -657,7 +671,9 @@ int pcm_stackgru_backward(const pcm_dims *dims,
         gb.count = 0;
         auto flush = [&]() -> int {
             if (gb.count == 0) return PCM_OK;
+            pcm_probe_begin(PCM_K_DW_GEMM);
             int q = pcm_gemm_launch(gb, gs2, gsb, gst);
+            pcm_probe_end(PCM_K_DW_GEMM);
             gb.count = 0;
             return q;
         };
@@ -897,9 +913,9 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                 g.gates = gates;
                 g.hprev = sv + lay.off_hs[l] + (size_t)t * lay.hs_step();
                 g.lengths = lengths; g.B = Bt; g.H = H; g.Hp = Hp; g.t = t;
-                pcm_probe_begin(PCM_K_GATE_BWD, st);
+                pcm_probe_begin(PCM_K_GATE_BWD);
                 pcm_launch_gate_bwd(g, st);
-                pcm_probe_end(PCM_K_GATE_BWD, st);
+                pcm_probe_end(PCM_K_GATE_BWD);
             }
 
             if (fused_bwd) {
@@ -927,9 +943,9 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                                    (size_t)t * lay.hs_step();
                 }
                 if (l == 0) dtop_parts = pcm_cell_bwd_xparts(cb);
-                pcm_probe_begin(PCM_K_GEMM, st);
+                pcm_probe_begin(PCM_K_CELL_BWD, l);
                 pcm_launch_cell_bwd(cb, st);
-                pcm_probe_end(PCM_K_GEMM, st);
+                pcm_probe_end(PCM_K_CELL_BWD, l);
                 continue;
             }
             // generic path (H not a multiple of 64):
@@ -961,9 +977,7 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                                             dtop, lay.Wp, Bt, lay.W, 3 * H);
                 gb.p[gb.count++] = p2;
             }
-            pcm_probe_begin(PCM_K_GEMM, st);
             rc = pcm_gemm_launch(gb, gs, gsb, st);
-            pcm_probe_end(PCM_K_GEMM, st);
             if (rc) return rc;
             if (!seg_ok) {
                 GemmBatch g2;
@@ -1007,9 +1021,10 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                                     (size_t)(t - 1) * lay.hs_step()
                               : nullptr;
             s.ctrl_w = weights->ctrl_w; s.push_w = weights->push_w;
-            pcm_probe_begin(PCM_K_STACK_BWD, st);
-            pcm_launch_stack_bwd(s, st);
-            pcm_probe_end(PCM_K_STACK_BWD, st);
+            pcm_probe_begin(PCM_K_STACK_BWD);
+            rc = pcm_launch_stack_bwd(s, st);
+            pcm_probe_end(PCM_K_STACK_BWD);
+            if (rc) return rc;
             cur ^= 1;
         }
         // the control gradients of step t feed the gate kernel of step t-1
@@ -1158,6 +1173,10 @@ int pcm_stackgru_generate(const pcm_dims *dims,
     PCM_REQUIRE(workspace_bytes >= g.total * sizeof(float), PCM_ENOMEM,
                 "stackgru_generate: workspace %zu < %zu bytes", workspace_bytes,
                 g.total * sizeof(float));
+    if (lay.use_stack) {
+        rc = pcm_stack_fwd_check(lay.D, lay.W, lay.H, lay.AVW);
+        if (rc) return rc;
+    }
     hipStream_t st = (hipStream_t)stream;
     float *ws = (float *)workspace;
     const int B = lay.B, H = lay.H, Hp = lay.Hp, L = lay.L, V = lay.V;

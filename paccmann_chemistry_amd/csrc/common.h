@@ -1,6 +1,7 @@
 // Shared declarations of libpaccmann_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
 
@@ -87,22 +88,42 @@ int pcm_colsum_launch(const float *X, long long ldx, int M, int N, float *out,
                       size_t scratch_bytes, hipStream_t stream);
 
 // ---- launch-duration probe (bench.py roofline) ---------------------------------
-// When enabled for one kernel id, every launch of that kernel is bracketed by
-// hipEvents on its stream; pcm_probe_read() sums the elapsed times.
-#define PCM_K_CELL_FWD 1
+// When enabled for one kernel id, the launches of that kernel go through
+// hipExtLaunchKernelGGL with a (start, stop) event pair bound to the kernel's own
+// dispatch: the elapsed time is the kernel's begin -> end on the device (the
+// timestamps a rocprofv3 kernel trace reports), with no marker packets on the
+// stream.  pcm_probe_read() sums the elapsed times.
+#define PCM_K_CELL_FWD 1     // 11: layer 0 only, 12: layers >= 1 only
 #define PCM_K_STACK_FWD 2
 #define PCM_K_GATE_BWD 3
 #define PCM_K_STACK_BWD 4
-#define PCM_K_GEMM 5
+#define PCM_K_CELL_BWD 5     // 51: layer 0 only, 52: layers >= 1 only
+#define PCM_K_DW_GEMM 6      // K-major weight-gradient GEMM (main kernel)
 extern int g_pcm_probe_id;
-void pcm_probe_begin_(int id, hipStream_t st);
-void pcm_probe_end_(int id, hipStream_t st);
-static inline void pcm_probe_begin(int id, hipStream_t st) {
-    if (g_pcm_probe_id == id) pcm_probe_begin_(id, st);
+extern hipEvent_t g_pcm_probe_start, g_pcm_probe_stop;  // set while a probed
+                                                        // launch is enqueued
+void pcm_probe_begin_(void);
+void pcm_probe_end_(void);
+static inline bool pcm_probe_match(int id, int layer) {
+    return g_pcm_probe_id == id ||
+           (layer >= 0 && g_pcm_probe_id == id * 10 + (layer == 0 ? 1 : 2));
 }
-static inline void pcm_probe_end(int id, hipStream_t st) {
-    if (g_pcm_probe_id == id) pcm_probe_end_(id, st);
+static inline void pcm_probe_begin(int id, int layer = -1) {
+    if (g_pcm_probe_id && pcm_probe_match(id, layer)) pcm_probe_begin_();
 }
+static inline void pcm_probe_end(int id, int layer = -1) {
+    if (g_pcm_probe_id && pcm_probe_match(id, layer)) pcm_probe_end_();
+}
+// every kernel a probe can name is launched through this
+#define PCM_LAUNCH(kernel, grid, block, shmem, stream, ...)                     \
+    do {                                                                        \
+        if (g_pcm_probe_start)                                                  \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream,           \
+                                  g_pcm_probe_start, g_pcm_probe_stop, 0,       \
+                                  __VA_ARGS__);                                 \
+        else                                                                    \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); \
+    } while (0)
 
 // ---- device helpers -------------------------------------------------------------
 // n / d for 0 <= n < 2^20 through a float reciprocal (3 VALU instead of ~35):

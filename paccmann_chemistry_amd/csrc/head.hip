@@ -12,10 +12,15 @@ int grid_for(long long n) {
 
 // active rows per step: cnt[t] = #{b : lengths[b] > t}  (B when lengths == null)
 __global__ __launch_bounds__(256) void step_count_kernel(const int32_t *lengths,
+                                                         const float *step_weight,
                                                          int T, int B,
                                                          float *inv_cnt) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= T) return;
+    if (step_weight) {   // caller-supplied divisor (data parallel: global counts)
+        inv_cnt[t] = step_weight[t];
+        return;
+    }
     int c = B;
     if (lengths) {
         c = 0;
@@ -403,23 +408,19 @@ __global__ __launch_bounds__(256) void prepare_batch_kernel(
     }
 }
 
-extern "C" {
-
-int pcm_softmax_ce(const float *logits, const int64_t *targets,
-                   const int32_t *lengths, int32_t steps, int32_t batch,
-                   int32_t vocab, float *loss, int64_t *argmax, float *dlogits,
-                   float *scratch, int32_t *status, void *stream) {
-    PCM_REQUIRE(logits && targets && loss && scratch, PCM_EINVAL,
-                "softmax_ce: null pointer");
-    PCM_REQUIRE(steps > 0 && batch > 0 && vocab > 0, PCM_EINVAL,
-                "softmax_ce: bad shape T=%d B=%d V=%d", steps, batch, vocab);
-    hipStream_t st = (hipStream_t)stream;
+// Body of pcm_softmax_ce.  scratch: T*B row
+// losses followed by T reciprocal counts; every word the kernels read is written
+// by this call first, so the buffer needs no clearing between calls.
+static int softmax_ce_enqueue(const float *logits, const int64_t *targets,
+                              const int32_t *lengths, const float *step_weight,
+                              int32_t steps, int32_t batch, int32_t vocab,
+                              float *loss, int64_t *argmax, float *dlogits,
+                              float *scratch, int32_t *status, hipStream_t st) {
     const long long rows = (long long)steps * batch;
-    // scratch: rows row losses followed by `steps` reciprocal counts
     float *rowloss = scratch;
     float *inv_cnt = scratch + rows;
     hipLaunchKernelGGL(step_count_kernel, dim3((steps + 255) / 256), dim3(256),
-                       0, st, lengths, steps, batch, inv_cnt);
+                       0, st, lengths, step_weight, steps, batch, inv_cnt);
     const int blocks = (int)((rows + 3) / 4 > 8192 ? 8192 : (rows + 3) / 4);
     hipLaunchKernelGGL(softmax_ce_kernel, dim3(blocks), dim3(256), 0, st, logits,
                        targets, lengths, steps, batch, vocab, inv_cnt, rowloss,
@@ -427,6 +428,22 @@ int pcm_softmax_ce(const float *logits, const int64_t *targets,
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, rowloss, rows,
                        1.0f, loss);
     return pcm_check_launch("softmax_ce");
+}
+
+extern "C" {
+
+int pcm_softmax_ce(const float *logits, const int64_t *targets,
+                   const int32_t *lengths, const float *step_weight,
+                   int32_t steps, int32_t batch,
+                   int32_t vocab, float *loss, int64_t *argmax, float *dlogits,
+                   float *scratch, int32_t *status, void *stream) {
+    PCM_REQUIRE(logits && targets && loss && scratch, PCM_EINVAL,
+                "softmax_ce: null pointer");
+    PCM_REQUIRE(steps > 0 && batch > 0 && vocab > 0, PCM_EINVAL,
+                "softmax_ce: bad shape T=%d B=%d V=%d", steps, batch, vocab);
+    return softmax_ce_enqueue(logits, targets, lengths, step_weight, steps, batch,
+                              vocab, loss, argmax, dlogits, scratch, status,
+                              (hipStream_t)stream);
 }
 
 int pcm_reparam_forward(const float *mu, const float *logvar, const float *eps,

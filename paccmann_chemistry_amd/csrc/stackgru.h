@@ -89,6 +89,12 @@ struct StackFwdArgs {
     int B, H, Hp, D, W, Wp, AVW, t;
 };
 int pcm_launch_stack_fwd(const StackFwdArgs &a, hipStream_t stream);
+// The stack kernels stage whole [D, W] stacks in LDS: PCM_OK if one batch row
+// fits the dynamic LDS of a block, else PCM_EINVAL with the limit in the
+// message.  Checked once per call, before anything is launched.
+#define PCM_STACK_LDS_BYTES (64 * 1024)
+int pcm_stack_fwd_check(int D, int W, int H, int AVW);
+int pcm_stack_bwd_check(int D, int W, int AVW);
 
 struct PackArgs {
     const float *w_ih, *w_hh, *b_ih, *b_hh;

@@ -687,7 +687,7 @@ int grid_for(long long n) {
 }  // namespace
 
 int pcm_launch_gate_bwd(const GateBwdArgs &a, hipStream_t stream) {
-    hipLaunchKernelGGL(gate_bwd_kernel, dim3((a.H + 255) / 256, a.B), dim3(256),
+    PCM_LAUNCH(gate_bwd_kernel, dim3((a.H + 255) / 256, a.B), dim3(256),
                        0, stream, a);
     return 0;
 }
@@ -733,13 +733,13 @@ int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream) {
     b.reg_rows = (nbt + 1) / 2;
     dim3 grid(8 * b.reg_cols * b.reg_rows);
     if (xpart)
-        hipLaunchKernelGGL((gru_cell_bwd_kernel<32, 3, true>), grid, dim3(512), 0,
+        PCM_LAUNCH((gru_cell_bwd_kernel<32, 3, true>), grid, dim3(512), 0,
                            stream, b);
     else if (narrow)
-        hipLaunchKernelGGL((gru_cell_bwd_kernel<32, 3>), grid, dim3(512), 0,
+        PCM_LAUNCH((gru_cell_bwd_kernel<32, 3>), grid, dim3(512), 0,
                            stream, b);
     else
-        hipLaunchKernelGGL((gru_cell_bwd_kernel<64, 2>), grid, dim3(512), 0,
+        PCM_LAUNCH((gru_cell_bwd_kernel<64, 2>), grid, dim3(512), 0,
                            stream, b);
     return 0;
 }
@@ -751,12 +751,25 @@ int pcm_launch_packT(const PackTArgs &a, hipStream_t stream) {
     return 0;
 }
 
+// LDS bytes one batch row of the stack adjoint stages (saved stack, running
+// stack gradient, controls and their gradients, wave partials)
+static size_t stack_bwd_row_bytes(int D, int W, int AVW) {
+    const int DWp = (D * W + 3) & ~3;
+    return (size_t)(2 * DWp + 2 * AVW + 3 * 8) * sizeof(float);
+}
+
+int pcm_stack_bwd_check(int D, int W, int AVW) {
+    PCM_REQUIRE(stack_bwd_row_bytes(D, W, AVW) <= PCM_STACK_LDS_BYTES, PCM_EINVAL,
+                "stack step (backward): stack %dx%d exceeds the %d KiB LDS row "
+                "cache (needs (2*D*W + 2*W + 30) * 4 bytes per row)", D, W,
+                PCM_STACK_LDS_BYTES / 1024);
+    return PCM_OK;
+}
+
 int pcm_launch_stack_bwd(const StackBwdArgs &a, hipStream_t stream) {
-    const int DWp = (a.D * a.W + 3) & ~3;
-    const size_t row_bytes = (size_t)(2 * DWp + 2 * a.AVW + 3 * 8) * sizeof(float);
-    PCM_REQUIRE(2 * row_bytes <= 64 * 1024, PCM_EINVAL,
-                "stack step (backward): stack %dx%d exceeds the 64 KiB LDS "
-                "row cache", a.D, a.W);
+    const size_t row_bytes = stack_bwd_row_bytes(a.D, a.W, a.AVW);
+    int rc = pcm_stack_bwd_check(a.D, a.W, a.AVW);
+    if (rc) return rc;
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess)
@@ -767,11 +780,11 @@ int pcm_launch_stack_bwd(const StackBwdArgs &a, hipStream_t stream) {
     // one row per block while that is at most two blocks per CU (batch 512:
     // 8.2 us against 9.5 for two rows), else two
     const int rows = a.gate_mode ? (a.gate_B > a.B ? a.gate_B : a.B) : a.B;
-    if (rows <= 2 * cus)
-        hipLaunchKernelGGL(stack_bwd_kernel<1>, dim3(rows), dim3(BTHREADS),
+    if (rows <= 2 * cus || 2 * row_bytes > PCM_STACK_LDS_BYTES)
+        PCM_LAUNCH(stack_bwd_kernel<1>, dim3(rows), dim3(BTHREADS),
                            row_bytes, stream, a);
     else
-        hipLaunchKernelGGL(stack_bwd_kernel<2>, dim3((rows + 1) / 2),
+        PCM_LAUNCH(stack_bwd_kernel<2>, dim3((rows + 1) / 2),
                            dim3(BTHREADS), 2 * row_bytes, stream, a);
     return 0;
 }

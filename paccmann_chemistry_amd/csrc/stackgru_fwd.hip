@@ -1061,20 +1061,34 @@ int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
     const bool narrow = force ? force == 16 : load_narrow < load_wide;
     if (narrow) {
         dim3 grid(a.Hn / NCN, nbt);
-        hipLaunchKernelGGL(gru_cell_fwd16_kernel, grid, dim3(512), 0, stream, a);
+        PCM_LAUNCH(gru_cell_fwd16_kernel, grid, dim3(512), 0, stream, a);
     } else {
         dim3 grid(a.Hn / CN, nbt);
-        hipLaunchKernelGGL(gru_cell_fwd_kernel, grid, dim3(512), 0, stream, a);
+        PCM_LAUNCH(gru_cell_fwd_kernel, grid, dim3(512), 0, stream, a);
     }
     return 0;
 }
 
+// LDS bytes one batch row of the forward stack step stages (previous stack,
+// top-layer hidden row, controls)
+static size_t stack_fwd_row_bytes(int D, int W, int H, int AVW) {
+    const int DWp = (D * W + 3) & ~3;
+    return (size_t)(DWp + H + AVW) * sizeof(float);
+}
+
+int pcm_stack_fwd_check(int D, int W, int H, int AVW) {
+    PCM_REQUIRE(stack_fwd_row_bytes(D, W, H, AVW) <= PCM_STACK_LDS_BYTES,
+                PCM_EINVAL,
+                "stack step: stack %dx%d + hidden %d exceed the %d KiB LDS row "
+                "cache (needs (D*W + H + W + 3) * 4 bytes per row)", D, W, H,
+                PCM_STACK_LDS_BYTES / 1024);
+    return PCM_OK;
+}
+
 int pcm_launch_stack_fwd(const StackFwdArgs &a, hipStream_t stream) {
-    const int DWp = (a.D * a.W + 3) & ~3;
-    const size_t row_bytes = (size_t)(DWp + a.H + a.AVW) * sizeof(float);
-    PCM_REQUIRE(2 * row_bytes <= 64 * 1024, PCM_EINVAL,
-                "stack step: stack %dx%d + hidden %d exceed the 64 KiB LDS "
-                "row cache", a.D, a.W, a.H);
+    const size_t row_bytes = stack_fwd_row_bytes(a.D, a.W, a.H, a.AVW);
+    int rc = pcm_stack_fwd_check(a.D, a.W, a.H, a.AVW);
+    if (rc) return rc;
     static const int force = [] {
         const char *e = getenv("PCM_STACK_LEAN");  // 0 / 1: force a variant
         return e ? atoi(e) : -1;
@@ -1093,26 +1107,28 @@ int pcm_launch_stack_fwd(const StackFwdArgs &a, hipStream_t stream) {
     }();
     if (a.B >= mfma_rows && (a.H % 32) == 0 && (a.Hp % 4) == 0 &&
         3 + a.W <= 64 && ((a.D * a.W) & 3) == 0 && a.AVW <= 64) {
-        hipLaunchKernelGGL(stack_step_fwd_mfma_kernel,
+        PCM_LAUNCH(stack_step_fwd_mfma_kernel,
                            dim3((a.B + MROWS - 1) / MROWS), dim3(512), 0, stream,
                            a);
         return 0;
     }
-    const int rows = a.B <= 2 * cus ? 1 : 2;
+    // (two rows per block only while both fit the LDS row cache)
+    const int rows =
+        (a.B <= 2 * cus || 2 * row_bytes > PCM_STACK_LDS_BYTES) ? 1 : 2;
     const dim3 grid((a.B + rows - 1) / rows);
     const bool lean = force >= 0 ? force == 1 : (int)grid.x > cus;
     const size_t lds = rows * row_bytes;
     if (rows == 1 && lean)
-        hipLaunchKernelGGL((stack_step_fwd_kernel<true, 1>), grid,
+        PCM_LAUNCH((stack_step_fwd_kernel<true, 1>), grid,
                            dim3(STHREADS), lds, stream, a);
     else if (rows == 1)
-        hipLaunchKernelGGL((stack_step_fwd_kernel<false, 1>), grid,
+        PCM_LAUNCH((stack_step_fwd_kernel<false, 1>), grid,
                            dim3(STHREADS), lds, stream, a);
     else if (lean)
-        hipLaunchKernelGGL((stack_step_fwd_kernel<true, 2>), grid,
+        PCM_LAUNCH((stack_step_fwd_kernel<true, 2>), grid,
                            dim3(STHREADS), lds, stream, a);
     else
-        hipLaunchKernelGGL((stack_step_fwd_kernel<false, 2>), grid,
+        PCM_LAUNCH((stack_step_fwd_kernel<false, 2>), grid,
                            dim3(STHREADS), lds, stream, a);
     return 0;
 }

@@ -295,7 +295,8 @@ class DecoderHeadFn(torch.autograd.Function):
     """loss, argmax[B,T], logits[T,B,V] = head(out[T,B,H], W, b, targets)."""
 
     @staticmethod
-    def forward(ctx, out, weight, bias, targets, lengths, status):
+    def forward(ctx, out, weight, bias, targets, lengths, status,
+                step_weight=None):
         lib = load()
         _f32(out, 'decoder outputs')
         steps, batch, hid = out.shape
@@ -319,11 +320,18 @@ class DecoderHeadFn(torch.autograd.Function):
         want_grad = any(ctx.needs_input_grad[:3])
         dlogits = torch.empty_like(logits) if want_grad else None
         scratch = torch.empty(m + steps, device=dev)
+        if step_weight is not None:
+            # data parallel: 1 / (rows active at step t over all ranks)
+            step_weight = step_weight.to(
+                device=dev, dtype=torch.float32
+            ).contiguous()
+            if step_weight.numel() != steps:
+                raise ValueError('step_weight must have one entry per step')
         check(
             lib.pcm_softmax_ce(
-                ptr(logits), ptr(targets), ptr(lengths), steps, batch, vocab,
-                ptr(loss), ptr(argmax), ptr(dlogits), ptr(scratch),
-                ptr(status), stream_ptr(dev)
+                ptr(logits), ptr(targets), ptr(lengths), ptr(step_weight),
+                steps, batch, vocab, ptr(loss), ptr(argmax), ptr(dlogits),
+                ptr(scratch), ptr(status), stream_ptr(dev)
             ), 'pcm_softmax_ce'
         )
         ctx.save_for_backward(x2, weight)
@@ -354,7 +362,7 @@ class DecoderHeadFn(torch.autograd.Function):
             ), 'pcm_linear_backward(output_layer)'
         )
         ctx.dlogits = None
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
 # --------------------------------------------------------------------------

@@ -1,0 +1,251 @@
+"""GPU parity at the sizes that are benchmarked (BASELINE.json configs 2, 4, 5).
+
+The launchers pick kernel variants by batch size (two blocks per CU for the
+layer-1 reverse cell, the 256-block layer-0 variant, one-row stack blocks, the
+MFMA stack step from 4096 rows on), so the variants the bench times are
+checked here at their real shapes:
+
+* B=512 x T=120 training step (forward + backward), every parameter gradient
+  against the oracle's autograd, without and with inter-layer dropout
+  (models/vae.py:571-599, training.py:147-153);
+* SamplingSearch.step (utils/search.py:124-141) bit-exact against the oracle's
+  distribution with the counter-hash uniforms regenerated in numpy;
+* B=4096 encoder-only and greedy decode rows against the same rows at B=4,
+  which the oracle checks.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import stackgru_oracle as O
+from oracle import weights as W
+from test_gpu_parity import (
+    GRAD_TOL, LOGIT_TOL, _build_vae, _cpu_dropout_masks, _dev, _rel_to_max
+)
+
+pytestmark = pytest.mark.gpu
+
+CONFIG = {
+    'latent_dim': 256, 'rnn_cell_size': 512, 'embedding_size': 60,
+    'vocab_size': 60, 'stack_width': 50, 'stack_depth': 50, 'n_layers': 2,
+    'dropout': 0.0, 'batch_size': 512, 'batch_mode': 'padded',
+    'embedding': 'one_hot', 'use_stack': True, 'bidirectional': False
+}
+SEQ_LEN = 120
+
+
+def _mix(x):
+    x = x + np.uint64(0x9E3779B97F4A7C15)
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def _uniform(seed, counters):
+    """numpy restatement of pcm_uniform (csrc/common.h)."""
+    with np.errstate(over='ignore'):
+        h = _mix(np.uint64(seed) ^ _mix(counters.astype(np.uint64)))
+    return (h >> np.uint64(40)).astype(np.float32) * np.float32(1 / 16777216)
+
+
+@pytest.mark.parametrize('dropout', [0.0, 0.2])
+def test_full_size_training_step_matches_oracle(dropout):
+    """The timed configuration itself: B=512, T=120, train mode.  Loss, mu,
+    per-step logits and EVERY parameter gradient against the oracle; with
+    dropout 0.2 the device masks (a pure function of seed, layer, t, b, j) are
+    regenerated in numpy and fed to the oracle."""
+    from paccmann_chemistry_amd import vae_loss_function
+    p = dict(CONFIG, dropout=dropout)
+    batch = p['batch_size']
+    sd = W.make_state_dict(p, 4100)
+    tokens = W.synthetic_tokens(SEQ_LEN, batch, p['vocab_size'], 4101)
+    targets = W.shifted_targets(tokens)
+    keep = np.random.default_rng(4102).random(SEQ_LEN) < 0.85
+    dec_tokens = tokens.clone()
+    dec_tokens[torch.from_numpy(~keep)] = 1   # whole-row word dropout
+    eps = torch.from_numpy(np.random.default_rng(4103).standard_normal(
+        (batch, p['latent_dim'])).astype(np.float32))
+    vae = _build_vae(p, sd)
+    seeds = {'encoder': 0x1234567, 'decoder': 0x7654321}
+    vae.encoder._next_seed = lambda: seeds['encoder']
+    vae.decoder._next_seed = lambda: seeds['decoder']
+    dev = _dev()
+    dec_loss, mu, logvar = vae(tokens.to(dev), dec_tokens.to(dev),
+                               targets.to(dev), eps=eps.to(dev))
+    total, _ = vae_loss_function(dec_loss, mu, logvar, kl_growth=0.003,
+                                 step=5000)
+    total.backward()
+    vae.check_tokens()
+
+    ref = {k: v.clone().requires_grad_('embedding' not in k)
+           for k, v in sd.items()}
+    enc_masks = dec_masks = None
+    if dropout > 0:
+        enc_masks = _cpu_dropout_masks(seeds['encoder'], SEQ_LEN, 2, batch,
+                                       512, dropout)
+        dec_masks = _cpu_dropout_masks(seeds['decoder'], SEQ_LEN, 2, batch,
+                                       512, dropout)
+    r_mu, r_logvar = O.encoder_forward(
+        O.sub_params(ref, 'encoder'), tokens, p['stack_depth'], None, True,
+        enc_masks)
+    z = O.reparameterize(r_mu, r_logvar, eps)
+    r_loss, r_logits, r_argmax = O.decoder_forward(
+        O.sub_params(ref, 'decoder'), z, dec_tokens, targets,
+        p['stack_depth'], None, True, dec_masks)
+    r_total, _ = O.vae_loss(r_loss, r_mu, r_logvar, 0.003, step=5000)
+    r_total.backward()
+
+    assert _rel_to_max(mu, r_mu) < 1e-5
+    assert _rel_to_max(vae.decoder.logits, r_logits) < LOGIT_TOL
+    assert abs(total.item() - r_total.item()) < 1e-5 * abs(r_total.item())
+    bad = {}
+    for name, param in vae.named_parameters():
+        if ref[name].grad is None:
+            continue
+        err = _rel_to_max(param.grad, ref[name].grad)
+        if not err < GRAD_TOL:
+            bad[name] = err
+    assert not bad, bad
+
+
+def test_sampling_tokens_bit_exact_against_oracle_distribution():
+    """SamplingSearch.step at the config model (V=60, H=512), B=70: the device
+    draw is a counter hash of (seed, step, row); with the same uniforms the
+    token must be the first index whose cumulative
+    oracle.sampling_probabilities(logits, T) exceeds the draw, at every step
+    of a 12-token generation (the oracle replays the generation with that
+    chooser, so the per-step logits are compared too)."""
+    import paccmann_chemistry_amd as P
+    p = dict(CONFIG, batch_size=70)
+    temperature, seed, gen_len = 0.8, 20241111, 12
+    sd = W.make_state_dict(p, 4200)
+    vae = _build_vae(p, sd, train=False)
+    z = torch.from_numpy(np.random.default_rng(4201).standard_normal(
+        (70, p['latent_dim'])).astype(np.float32))
+    prime = torch.tensor([2])
+    tokens, logits = vae.decoder.generate_from_latent(
+        z.unsqueeze(0).to(_dev()), prime.to(_dev()), torch.tensor([3]),
+        search=P.SamplingSearch(temperature=temperature),
+        generate_len=gen_len, seed=seed, return_logits=True
+    )
+    step_box = {'i': 0}
+    margins = []
+
+    def chooser(step_logits):
+        i = step_box['i']
+        step_box['i'] += 1
+        rows = np.arange(70, dtype=np.uint64)
+        u = _uniform(seed, (np.uint64(i) << np.uint64(32)) | rows)
+        probs = O.sampling_probabilities(step_logits, temperature)
+        cum = torch.cumsum(probs.double(), dim=1).numpy()
+        pick = (cum > u[:, None].astype(np.float64)).argmax(axis=1)
+        none = ~(cum > u[:, None]).any(axis=1)
+        pick[none] = cum.shape[1] - 1
+        margins.append(np.abs(cum - u[:, None]).min(axis=1))
+        return torch.from_numpy(pick).view(-1, 1)
+
+    with torch.no_grad():
+        r_tokens, r_logits = O.generate_from_latent(
+            O.sub_params(sd, 'decoder'), z, prime, gen_len, p['stack_depth'],
+            True, chooser)
+    margin = float(np.min(margins))
+    assert torch.equal(tokens.cpu(), r_tokens), (
+        f'smallest |cumulative - draw| over the run: {margin:.3e}')
+    assert _rel_to_max(logits, r_logits) < LOGIT_TOL
+    # the draws do move the choice away from the argmax
+    greedy = r_logits.argmax(dim=2).t()
+    assert (r_tokens[:, 1:] != greedy).float().mean().item() > 0.2
+
+
+def test_batch_4096_rows_match_small_batch():
+    """Config 4 / 5 shape (B=4096): encoder-only mu / logvar and 100 greedy
+    tokens.  Rows 0, 1023, 2048, 4095 of the big batch against the same
+    sequences / latents at B=4, and those against the oracle.  Covers the
+    MFMA stack step (>= 4096 rows) and the many-blocks-per-CU forward cell."""
+    from paccmann_chemistry_amd import GreedySearch
+    rows = [0, 1023, 2048, 4095]
+    p = dict(CONFIG, batch_size=4096)
+    sd = W.make_state_dict(p, 4300)
+    tokens = W.synthetic_tokens(SEQ_LEN, 4096, p['vocab_size'], 4301)
+    z = torch.from_numpy(np.random.default_rng(4302).standard_normal(
+        (4096, p['latent_dim'])).astype(np.float32))
+    prime, gen_len = torch.tensor([2]), 100
+    big = _build_vae(p, sd, train=False)
+    dev = _dev()
+    with torch.no_grad():
+        mu, logvar = big.encode(tokens.to(dev))
+        toks, logits = big.decoder.generate_from_latent(
+            z.unsqueeze(0).to(dev), prime.to(dev), torch.tensor([3]),
+            search=GreedySearch(), generate_len=gen_len, return_logits=True)
+    big.check_tokens()
+    mu, logvar = mu.cpu()[rows], logvar.cpu()[rows]
+    toks, logits = toks.cpu()[rows], logits.cpu()[:, rows]
+    del big
+    small = _build_vae(dict(p, batch_size=4), sd, train=False)
+    with torch.no_grad():
+        mu_s, logvar_s = small.encode(tokens[:, rows].to(dev))
+        toks_s, logits_s = small.decoder.generate_from_latent(
+            z[rows].unsqueeze(0).to(dev), prime.to(dev), torch.tensor([3]),
+            search=GreedySearch(), generate_len=gen_len, return_logits=True)
+    assert _rel_to_max(mu, mu_s) < 1e-5
+    assert _rel_to_max(logvar, logvar_s) < 1e-5
+    assert torch.equal(toks, toks_s.cpu())
+    assert _rel_to_max(logits, logits_s) < 1e-5
+    # the small batch against the oracle
+    with torch.no_grad():
+        r_mu, r_logvar = O.encoder_forward(
+            O.sub_params(sd, 'encoder'), tokens[:, rows], p['stack_depth'])
+        r_toks, r_logits = O.generate_from_latent(
+            O.sub_params(sd, 'decoder'), z[rows], prime, gen_len,
+            p['stack_depth'])
+    assert _rel_to_max(mu_s, r_mu) < 1e-4
+    assert _rel_to_max(logits_s, r_logits) < LOGIT_TOL
+    assert torch.equal(toks_s.cpu(), r_toks)
+
+
+def test_large_stack_gradients_and_limit():
+    """Stack sizes beyond the tuned 50x50: a 64x64 stack (one row per block in
+    both stack kernels) trains with oracle-matching gradients; a stack whose
+    row no longer fits the reverse pass's LDS row cache is refused by the
+    training-mode forward, before any launch, while the eval-mode forward
+    (smaller footprint) still runs and matches."""
+    import paccmann_chemistry_amd as P
+    from paccmann_chemistry_amd._lib import PaccmannHipError
+    base = {
+        'latent_dim': 16, 'rnn_cell_size': 64, 'embedding_size': 20,
+        'vocab_size': 20, 'stack_width': 64, 'stack_depth': 64, 'n_layers': 2,
+        'dropout': 0.0, 'batch_size': 6, 'batch_mode': 'padded',
+        'embedding': 'one_hot', 'use_stack': True, 'bidirectional': False
+    }
+    steps = 5
+    sd = W.make_state_dict(base, 4400)
+    enc_sd = O.sub_params(sd, 'encoder')
+    tokens = W.synthetic_tokens(steps, 6, 20, 4401)
+    enc = P.StackGRUEncoder(base)
+    enc.load_state_dict(enc_sd)
+    enc = enc.to(_dev()).train()
+    mu, logvar = enc.encoder_train_step(tokens.to(_dev()))
+    (mu.sum() + 0.5 * logvar.sum()).backward()
+    ref = {k: v.clone().requires_grad_('embedding' not in k)
+           for k, v in enc_sd.items()}
+    r_mu, r_logvar = O.encoder_forward(ref, tokens, 64)
+    (r_mu.sum() + 0.5 * r_logvar.sum()).backward()
+    assert _rel_to_max(mu, r_mu) < 1e-5
+    for name, param in enc.named_parameters():
+        if ref[name].grad is not None:
+            assert _rel_to_max(param.grad, ref[name].grad) < GRAD_TOL, name
+
+    # 130 x 64: 8320 floats per row; the reverse pass would need 2 x that
+    huge = dict(base, stack_depth=130)
+    sd = W.make_state_dict(huge, 4402)
+    enc_sd = O.sub_params(sd, 'encoder')
+    enc = P.StackGRUEncoder(huge)
+    enc.load_state_dict(enc_sd)
+    enc = enc.to(_dev()).train()
+    with pytest.raises(PaccmannHipError, match='LDS row cache'):
+        enc.encoder_train_step(tokens.to(_dev()))
+    enc.eval()
+    with torch.no_grad():
+        mu, _ = enc.encoder_train_step(tokens.to(_dev()))
+        r_mu, _ = O.encoder_forward(enc_sd, tokens, 130)
+    assert _rel_to_max(mu, r_mu) < 1e-5
