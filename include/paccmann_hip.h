@@ -233,6 +233,24 @@ int pcm_softmax_ce(const float *logits, const int64_t *targets,
                    int32_t vocab, float *loss, int64_t *argmax, float *dlogits,
                    float *scratch, int32_t *status, void *stream);
 
+/*
+ * pcm_softmax_ce for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving / evaluation loops, harnesses that forbid
+ * hipMalloc).  NO counterpart in the reference: the same computation with the
+ * T*B + T floats of scratch taken from a static per-GPU array inside the
+ * library instead of a caller workspace; it calls no hipMalloc / hipFree or
+ * any allocating routine.  Limits: steps*batch + steps <= PCM_CE_STATIC_MAX_FLOATS
+ * (PCM_EINVAL beyond it).  Every call on one GPU shares that GPU's array:
+ * calls that overlap in time on one GPU (different streams / threads) race;
+ * calls ordered on one stream are safe, nothing needs clearing in between.
+ */
+#define PCM_CE_STATIC_MAX_FLOATS (1 << 20) /* 4 MiB per GPU */
+int pcm_softmax_ce_static(const float *logits, const int64_t *targets,
+                          const int32_t *lengths, const float *step_weight,
+                          int32_t steps, int32_t batch, int32_t vocab,
+                          float *loss, int64_t *argmax, float *dlogits,
+                          int32_t *status, void *stream);
+
 /* Latent ---------------------------------------------------------------------*/
 
 /* z = eps * exp(0.5*logvar) + mu  (vae.py:538-540), n elements. */

@@ -90,6 +90,10 @@ PROTOTYPES = {
         ctypes.c_int,
         [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP]
     ),
+    'pcm_softmax_ce_static': (
+        ctypes.c_int,
+        [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP]
+    ),
     'pcm_reparam_forward': (ctypes.c_int, [_VP, _VP, _VP, _VP, _I64, _VP]),
     'pcm_reparam_backward': (
         ctypes.c_int, [_VP, _VP, _VP, _VP, _VP, _I64, _VP]

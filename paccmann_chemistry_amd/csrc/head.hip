@@ -1,6 +1,8 @@
 // Decoder head and latent kernels: fused softmax / cross-entropy / argmax over
 // every (step, row), reparameterisation, KL divergence, token choice for
 // generation (greedy / temperature sampling) and the Adam update.
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(256) void prepare_batch_kernel(
     }
 }
 
-// Body of pcm_softmax_ce.  scratch: T*B row
+// Shared body of pcm_softmax_ce / pcm_softmax_ce_static.  scratch: T*B row
 // losses followed by T reciprocal counts; every word the kernels read is written
 // by this call first, so the buffer needs no clearing between calls.
 static int softmax_ce_enqueue(const float *logits, const int64_t *targets,
@@ -430,6 +432,38 @@ static int softmax_ce_enqueue(const float *logits, const int64_t *targets,
     return pcm_check_launch("softmax_ce");
 }
 
+// ---- scratch of the entry point that allocates nothing -----------------------------
+// One array per GPU, part of the code object (each device the library runs on
+// holds its own copy until the process ends).  In host code the array's NAME is
+// only a handle: the device address is looked up once per device with
+// hipGetSymbolAddress and only that pointer is ever handed to a kernel.
+static __device__ __align__(256) float g_ce_scratch[PCM_CE_STATIC_MAX_FLOATS];
+constexpr int CE_MAX_DEVICES = 64;
+static float *g_ce_scratch_ptr[CE_MAX_DEVICES] = {};
+static std::mutex g_ce_scratch_mutex;
+
+// device address of the CURRENT device's copy (looked up on first use there)
+static int ce_static_scratch(float **out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    PCM_REQUIRE(e == hipSuccess, PCM_EDEVICE, "softmax_ce_static: %s",
+                hipGetErrorString(e));
+    PCM_REQUIRE(dev >= 0 && dev < CE_MAX_DEVICES, PCM_EDEVICE,
+                "softmax_ce_static: device %d outside 0..%d", dev,
+                CE_MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(g_ce_scratch_mutex);
+    if (!g_ce_scratch_ptr[dev]) {
+        void *p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_ce_scratch));
+        PCM_REQUIRE(e == hipSuccess && p, PCM_EDEVICE,
+                    "softmax_ce_static: hipGetSymbolAddress: %s",
+                    hipGetErrorString(e));
+        g_ce_scratch_ptr[dev] = (float *)p;
+    }
+    *out = g_ce_scratch_ptr[dev];
+    return PCM_OK;
+}
+
 extern "C" {
 
 int pcm_softmax_ce(const float *logits, const int64_t *targets,
@@ -441,6 +475,29 @@ int pcm_softmax_ce(const float *logits, const int64_t *targets,
                 "softmax_ce: null pointer");
     PCM_REQUIRE(steps > 0 && batch > 0 && vocab > 0, PCM_EINVAL,
                 "softmax_ce: bad shape T=%d B=%d V=%d", steps, batch, vocab);
+    return softmax_ce_enqueue(logits, targets, lengths, step_weight, steps, batch,
+                              vocab, loss, argmax, dlogits, scratch, status,
+                              (hipStream_t)stream);
+}
+
+int pcm_softmax_ce_static(const float *logits, const int64_t *targets,
+                          const int32_t *lengths, const float *step_weight,
+                          int32_t steps, int32_t batch, int32_t vocab,
+                          float *loss, int64_t *argmax, float *dlogits,
+                          int32_t *status, void *stream) {
+    PCM_REQUIRE(logits && targets && loss, PCM_EINVAL,
+                "softmax_ce_static: null pointer");
+    PCM_REQUIRE(steps > 0 && batch > 0 && vocab > 0, PCM_EINVAL,
+                "softmax_ce_static: bad shape T=%d B=%d V=%d", steps, batch,
+                vocab);
+    const long long need = (long long)steps * batch + steps;
+    PCM_REQUIRE(need <= (long long)PCM_CE_STATIC_MAX_FLOATS, PCM_EINVAL,
+                "softmax_ce_static: T*B + T = %lld floats of scratch exceed the "
+                "static maximum of %d (use pcm_softmax_ce with a caller "
+                "workspace)", need, (int)PCM_CE_STATIC_MAX_FLOATS);
+    float *scratch = nullptr;
+    int rc = ce_static_scratch(&scratch);
+    if (rc) return rc;
     return softmax_ce_enqueue(logits, targets, lengths, step_weight, steps, batch,
                               vocab, loss, argmax, dlogits, scratch, status,
                               (hipStream_t)stream);
