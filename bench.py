@@ -190,6 +190,9 @@ def main():
     torch.manual_seed(1234)
     vae = P.TeacherVAE(P.StackGRUEncoder(p), P.StackGRUDecoder(p)).to(dev)
     vae.train()
+    # every step's cross entropy is divided by the rows active over ALL ranks
+    # (exact for the ragged packed workload too; one all-reduce of T counts)
+    vae.decoder.global_batch_loss = use_dist
     # identical random-init weights on every rank (seeded above)
     tokens = W.synthetic_tokens(SEQ_LEN, args.batch, p['vocab_size'],
                                 1234 + rank).to(dev)
@@ -225,7 +228,7 @@ def main():
         dec_loss, mu, logvar = vae(tokens, dec_tokens, targets)
         kl = KLDivFn.apply(mu, logvar)
         kl_w = kl_weight(global_step, KL_GROWTH)
-        loss = dp.scale_losses(dec_loss, kl, kl_w)
+        loss = dp.scale_losses(dec_loss, kl, kl_w, global_share=use_dist)
         loss.backward()
         buckets.finish()
         optimizer.step()

@@ -303,6 +303,52 @@ int pcm_stackgru_generate(const pcm_dims *dims,
                           void *workspace, size_t workspace_bytes,
                           int32_t *status, void *stream);
 
+/*
+ * GreedySearch.step / SamplingSearch.step and their forward() forms
+ * (utils/search.py:66-87, 105-141) on logits that already live on the device:
+ * one token per row of logits[rows, vocab] -- the first maximum (greedy), or
+ * the first index whose cumulative softmax(logits / temperature) exceeds a
+ * counter-based uniform of (seed, step, row) (sampling: the batched form of
+ * the reference's per-row torch.multinomial loop).
+ */
+int pcm_search_step(const float *logits, int64_t rows, int32_t vocab,
+                    int32_t search, float temperature, uint64_t seed,
+                    int32_t step, int64_t *tokens_out, void *stream);
+
+size_t pcm_generate_beam_workspace_bytes(const pcm_dims *dims,
+                                         int32_t beam_width,
+                                         int32_t generate_len);
+/*
+ * StackGRUDecoder.generate_from_latent, beam branch (vae.py:439-488) with
+ * BeamSearch.step (utils/search.py:169-201, 247-275) on the device: the
+ * beam_width state copies are rows k*B + b of one batch of beam_width * B
+ * sequences; per generated token one fused StackGRU step over that batch,
+ * output_layer, and one beam step (softmax(logits / temperature), the
+ * top_tokens most probable tokens per beam, candidates ranked by
+ * score + log(p + eps) with ties in candidate order, the best beam_width
+ * kept).  As in the reference, a state copy stays with its slot; it does not
+ * follow the parent of the beam that lands there.
+ *
+ *   dims->batch  B (the true batch); beam_width 1..16
+ *   tokens_out       int64[B, generate_len]: the best-scoring sequence of
+ *                    each row, WITHOUT the prime (vae.py:485-488)
+ *   beam_tokens_out  int64[B, beam_width, generate_len] (nullable): every
+ *                    beam, best first; -1 where fewer beams exist
+ *   beam_scores_out  fp64[B, beam_width] (nullable): their scores (sums of
+ *                    log-probabilities, double like the reference's floats)
+ */
+int pcm_stackgru_generate_beam(const pcm_dims *dims,
+                               const pcm_stackgru_params *weights,
+                               const float *out_w, const float *out_b,
+                               const float *h0, int64_t h0_layer_stride,
+                               const int64_t *prime, int32_t prime_len,
+                               int32_t generate_len, int32_t beam_width,
+                               int32_t top_tokens, float temperature,
+                               int64_t *tokens_out, int64_t *beam_tokens_out,
+                               double *beam_scores_out, void *workspace,
+                               size_t workspace_bytes, int32_t *status,
+                               void *stream);
+
 /* Optimiser ------------------------------------------------------------------*/
 
 /*

@@ -242,6 +242,118 @@ def run_greedy_case(ref_vae, ref_search, name, p, seed, generate_len,
     print(f'{name}: tokens[0,:8] {tokens[0, :8].tolist()}')
 
 
+def run_beam_case(ref_vae, ref_search, name, p, seed, generate_len, width,
+                  top_tokens, temperature, store_weights=True):
+    """Beam branch of generate_from_latent (vae.py:439-488 with
+    search.py:144-275): the best-scoring sequence per row, plus every beam and
+    its score after the last step."""
+    p = dict(p)
+    p['dropout'] = 0.0
+    sd = W.make_state_dict(p, seed)
+    vae = build_reference_vae(ref_vae, p, sd)
+    vae.eval()
+    rng = np.random.default_rng(seed + 11)
+    B = p['batch_size']
+    z = torch.from_numpy(
+        rng.standard_normal((1, B, p['latent_dim'])).astype(np.float32)
+    )
+    prime = torch.tensor([2, 5]) if 'prime2' in name else torch.tensor([2])
+    search = ref_search.BeamSearch(
+        beam_width=width, temperature=temperature, top_tokens=top_tokens
+    )
+    kept = {}
+    real_step = search.step
+
+    def recording_step(logits, beams):
+        tokens, updated = real_step(logits, beams)
+        kept['beams'] = updated
+        return tokens, updated
+
+    search.step = recording_step
+    with torch.no_grad():
+        tokens = vae.decoder.generate_from_latent(
+            z, prime, torch.tensor([3]), search=search,
+            generate_len=generate_len
+        )
+    beams = kept['beams']
+    all_tokens = np.array(
+        [[[int(t) for t in beam[0]] for beam in row] for row in beams],
+        np.int64
+    )   # [B, width, G]
+    scores = np.array([[float(beam[1]) for beam in row] for row in beams],
+                      np.float64)
+    res = {
+        'z': z.numpy(), 'prime': prime.numpy(), 'tokens': tokens.numpy(),
+        'beam_tokens': all_tokens, 'beam_scores': scores,
+        'generate_len': np.int64(generate_len), 'seed': np.int64(seed),
+        'beam_width': np.int64(width), 'top_tokens': np.int64(top_tokens),
+        'temperature': np.float64(temperature),
+    }
+    for k, v in p.items():
+        res['p::' + k] = np.asarray(v)
+    if store_weights:
+        res.update(np_state(sd))
+    np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), **res)
+    print(f'{name}: best[0,:8] {tokens[0, :8].tolist()} '
+          f'score {scores[0, 0]:.6f}')
+
+
+def run_prepare_case(name, seed, packed, input_keep=0.7):
+    """Batch preparation (utils/utils.py:29-146 behind training.py:328-348):
+    the reference's own encoder / decoder / target sequences for a ragged,
+    length-sorted batch, with the Bernoulli word-dropout draws it took
+    recorded, so that the device kernel can be fed the same draws."""
+    from paccmann_chemistry.utils import utils as ref_utils
+    real = ref_utils.Bernoulli
+    draws = []
+
+    class Recording:
+        def __init__(self, probs):
+            self.dist = real(probs)
+
+        def sample(self, shape):
+            mask = self.dist.sample(shape)
+            draws.append(mask.clone())
+            return mask
+
+    rng = np.random.default_rng(seed)
+    lens = sorted(rng.integers(2, 40, size=23).tolist(), reverse=True)
+    batch = []
+    for n in lens:
+        body = rng.integers(4, 60, size=n - 2)
+        batch.append(torch.from_numpy(
+            np.concatenate([[2], body, [3]]).astype(np.int64)))
+    cpu = torch.device('cpu')
+    ref_utils.Bernoulli = Recording
+    try:
+        if packed:
+            enc, dec, tgt = ref_utils.packed_sequential_data_preparation(
+                batch, input_keep=input_keep, start_index=2, end_index=3,
+                device=cpu)
+            out = {
+                'enc': enc.data.numpy(), 'dec': dec.data.numpy(),
+                'tgt': tgt.data.numpy(),
+                'batch_sizes': enc.batch_sizes.numpy(),
+            }
+        else:
+            padded = torch.nn.utils.rnn.pad_sequence(batch)
+            enc, dec, tgt = ref_utils.sequential_data_preparation(
+                padded, input_keep=input_keep, start_index=2, end_index=3,
+                device=cpu)
+            out = {'enc': enc.numpy(), 'dec': dec.numpy(), 'tgt': tgt.numpy()}
+    finally:
+        ref_utils.Bernoulli = real
+    keep = torch.cat([d.reshape(-1) for d in draws]).numpy().astype(np.uint8)
+    out.update({
+        'flat': torch.cat(batch).numpy(),
+        'offsets': np.concatenate([[0], np.cumsum(lens)]).astype(np.int64),
+        'keep': keep, 'input_keep': np.float64(input_keep),
+        'packed': np.int64(packed), 'seed': np.int64(seed),
+    })
+    np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), **out)
+    print(f'{name}: {len(lens)} samples, {int(keep.sum())}/{keep.size} kept')
+
+
 def run_kl_weight_case(name):
     from paccmann_chemistry.utils.utils import kl_weight
     steps = np.array([0, 1, 10, 100, 1000, 5000, 9000, 20000], np.int64)
@@ -345,6 +457,18 @@ def main():
         )
     if want('kl_weight'):
         run_kl_weight_case('kl_weight')
+    if want('prepare'):
+        run_prepare_case('prepare_padded', 500, False)
+        run_prepare_case('prepare_packed', 501, True)
+    if want('beam_tiny'):
+        run_beam_case(ref_vae, ref_search, 'beam_tiny', tiny(), 410, 14, 3, 5,
+                      1.0)
+        run_beam_case(ref_vae, ref_search, 'beam_tiny_prime2_t07',
+                      tiny(embedding='learned', batch_size=5), 411, 10, 4, 7,
+                      0.7)
+    if want('beam_config'):
+        run_beam_case(ref_vae, ref_search, 'beam_config', dict(CONFIG), 412,
+                      40, 3, 5, 1.0, store_weights=False)
 
 
 if __name__ == '__main__':

@@ -19,6 +19,8 @@ the reference (citations are ``path:line`` under the reference checkout):
   ``utils/utils.py:246-264``
 * greedy / sampling step ... ``utils/search.py:76-87,124-141``
 * generate_from_latent ..... ``models/vae.py:391-468``
+* beam search .............. ``utils/search.py:169-201,247-275`` with the beam
+  branch of ``models/vae.py:439-488``
 
 Parity pinning: the functions below are checked against outputs of the
 reference itself, generated in the build container by ``oracle/make_golden.py``
@@ -380,3 +382,76 @@ def generate_from_latent(
         generated = torch.cat((generated, top.view(-1, 1)), dim=1)
         all_logits.append(logits)
     return generated, torch.stack(all_logits)
+
+
+def beam_step(probabilities, beams, beam_width, top_tokens):
+    """utils/search.py:169-201 for one batch row: ``probabilities`` [slots, V]
+    (fp32 tensor), ``beams`` a list of [token list, score].  Each (slot, beam)
+    pair -- zip() stops at the shorter of the two -- contributes its
+    ``top_tokens`` most probable tokens; candidates are ranked by
+    score + log(p + eps), ties in candidate order (Python's sort is stable),
+    and the best ``beam_width`` survive."""
+    eps = 2.220446049250313e-16   # sys.float_info.epsilon
+    candidates = []
+    for probability, (sequence, score) in zip(probabilities, beams):
+        order = torch.argsort(-probability, stable=True)[:top_tokens]
+        for token in order.tolist():
+            # p + eps stays fp32 (tensor + Python scalar), the log is a double
+            bumped = float(probability[token] + eps)
+            candidates.append([sequence + [token], score + math.log(bumped)])
+    ranked = sorted(candidates, key=lambda pair: pair[1], reverse=True)
+    return ranked[:beam_width]
+
+
+def generate_from_latent_beam(
+    params, latent_z, prime, generate_len, stack_depth, beam_width,
+    top_tokens, temperature=1.0, use_stack=True
+):
+    """Beam branch of vae.py:439-488, eval mode.  latent_z [B,Z]; prime
+    i64[P].  Returns (best tokens i64[B,G] -- no prime, vae.py:485-488 --,
+    beams: per row a list of [token list, score], best first).
+
+    The reference keeps ``beam_width`` copies of (token, hidden, stack); copy k
+    is fed the last token of beam k after every step and is NOT re-pointed at
+    that beam's parent state; when fewer beams than copies exist, zip() drops
+    the surplus copies for good (vae.py:471-483)."""
+    n_layers = n_layers_of(params)
+    batch = latent_z.shape[0]
+    h0 = (
+        latent_z @ params['latent_to_hidden.weight'].t() +
+        params['latent_to_hidden.bias']
+    )
+    hidden = h0.unsqueeze(0).repeat(n_layers, 1, 1)
+    _, stack = _zeros_state(params, batch, stack_depth)
+    for p in range(prime.numel() - 1):
+        _, hidden, stack = stackgru_step(
+            params, prime[p].repeat(batch), hidden, stack, use_stack
+        )
+    tokens = [prime[-1].repeat(batch) for _ in range(beam_width)]
+    hiddens = [hidden.clone() for _ in range(beam_width)]
+    stacks = [stack.clone() for _ in range(beam_width)]
+    beams = [[[list(), 0.0]] for _ in range(batch)]
+    for _ in range(generate_len):
+        logits = []
+        slots = min(len(tokens), len(hiddens))
+        for k in range(slots):
+            out, hiddens[k], stacks[k] = stackgru_step(
+                params, tokens[k], hiddens[k], stacks[k], use_stack
+            )
+            logits.append(out @ params['output_layer.weight'].t() +
+                          params['output_layer.bias'])
+        hiddens, stacks = hiddens[:slots], stacks[:slots]
+        probabilities = torch.softmax(
+            torch.stack(logits).div(temperature), 2
+        )   # [slots, B, V]
+        beams = [
+            beam_step(probabilities[:, b], beams[b], beam_width, top_tokens)
+            for b in range(batch)
+        ]
+        alive = len(beams[0])
+        tokens = [
+            torch.tensor([beams[b][k][0][-1] for b in range(batch)])
+            for k in range(alive)
+        ]
+    best = torch.tensor([beams[b][0][0] for b in range(batch)])
+    return best, beams

@@ -108,6 +108,16 @@ PROTOTYPES = {
             _F32, _U64, _VP, _VP, _VP, _SZ, _VP, _VP
         ]
     ),
+    'pcm_search_step': (
+        ctypes.c_int, [_VP, _I64, _I32, _I32, _F32, _U64, _I32, _VP, _VP]
+    ),
+    'pcm_generate_beam_workspace_bytes': (_SZ, [_DIMS_P, _I32, _I32]),
+    'pcm_stackgru_generate_beam': (
+        ctypes.c_int, [
+            _DIMS_P, _PARAMS_P, _VP, _VP, _VP, _I64, _VP, _I32, _I32, _I32,
+            _I32, _F32, _VP, _VP, _VP, _VP, _SZ, _VP, _VP
+        ]
+    ),
     'pcm_prepare_batch': (
         ctypes.c_int, [
             _VP, _VP, _I32, _I32, _I32, _VP, _F32, _U64, _VP, _I64, _VP, _VP,

@@ -1267,3 +1267,178 @@ int pcm_stackgru_generate(const pcm_dims *dims,
 }
 
 }  // extern "C"
+
+// ---- beam-search generation ---------------------------------------------------------
+// The beam branch of generate_from_latent keeps beam_width copies of the
+// recurrent state (vae.py:442-453); here they are the rows k * B + b of ONE
+// batch of beam_width * B sequences, so a beam step is the ordinary fused step
+// over that batch, one output-layer GEMM and one beam_step_kernel launch.
+struct BeamLayout {
+    GenLayout g;           // state of the beam_width * B rows
+    size_t off_scores;     // double[B][width]
+    size_t off_hist_tok;   // int32[G][B][width]
+    size_t off_hist_par;   // int32[G][B][width]
+    size_t total;          // floats
+};
+
+static int beam_layout(const pcm_dims *dims, int width, int generate_len,
+                       BeamLayout *o) {
+    PCM_REQUIRE(dims, PCM_EINVAL, "dims is null");
+    PCM_REQUIRE(width >= 1 && width <= 16, PCM_EINVAL,
+                "beam_width=%d outside 1..16", width);
+    PCM_REQUIRE(generate_len >= 0, PCM_EINVAL, "generate_len=%d", generate_len);
+    PCM_REQUIRE((long long)dims->batch * width < (1ll << 24), PCM_EINVAL,
+                "batch x beam_width too large");
+    pcm_dims big = *dims;
+    big.batch = dims->batch * width;
+    int rc = gen_layout(&big, &o->g);
+    if (rc) return rc;
+    size_t off = o->g.total;
+    const size_t bw = (size_t)dims->batch * width;
+    o->off_scores = take(off, 2 * bw);
+    o->off_hist_tok = take(off, bw * (generate_len > 0 ? generate_len : 1));
+    o->off_hist_par = take(off, bw * (generate_len > 0 ? generate_len : 1));
+    o->total = off;
+    return PCM_OK;
+}
+
+extern "C" {
+
+size_t pcm_generate_beam_workspace_bytes(const pcm_dims *dims,
+                                         int32_t beam_width,
+                                         int32_t generate_len) {
+    BeamLayout bl;
+    if (beam_layout(dims, beam_width, generate_len, &bl)) return 0;
+    return bl.total * sizeof(float);
+}
+
+int pcm_stackgru_generate_beam(const pcm_dims *dims,
+                               const pcm_stackgru_params *weights,
+                               const float *out_w, const float *out_b,
+                               const float *h0, int64_t h0_layer_stride,
+                               const int64_t *prime, int32_t prime_len,
+                               int32_t generate_len, int32_t beam_width,
+                               int32_t top_tokens, float temperature,
+                               int64_t *tokens_out, int64_t *beam_tokens_out,
+                               double *beam_scores_out, void *workspace,
+                               size_t workspace_bytes, int32_t *status,
+                               void *stream) {
+    BeamLayout bl;
+    int rc = beam_layout(dims, beam_width, generate_len, &bl);
+    if (rc) return rc;
+    GenLayout &g = bl.g;
+    SGLayout &lay = g.lay;   // lay.B = beam_width * B
+    rc = check_params(lay, weights, "stackgru_generate_beam");
+    if (rc) return rc;
+    PCM_REQUIRE(out_w && prime && tokens_out && workspace, PCM_EINVAL,
+                "stackgru_generate_beam: null pointer");
+    PCM_REQUIRE(prime_len >= 1 && generate_len >= 1, PCM_EINVAL,
+                "stackgru_generate_beam: prime_len=%d generate_len=%d",
+                prime_len, generate_len);
+    PCM_REQUIRE(top_tokens >= 1 && temperature > 0.f, PCM_EINVAL,
+                "stackgru_generate_beam: top_tokens=%d temperature=%f",
+                top_tokens, temperature);
+    PCM_REQUIRE(workspace_bytes >= bl.total * sizeof(float), PCM_ENOMEM,
+                "stackgru_generate_beam: workspace %zu < %zu bytes",
+                workspace_bytes, bl.total * sizeof(float));
+    PCM_REQUIRE(((uintptr_t)workspace & 15) == 0, PCM_EINVAL,
+                "stackgru_generate_beam: workspace must be 16-byte aligned");
+    if (lay.use_stack) {
+        rc = pcm_stack_fwd_check(lay.D, lay.W, lay.H, lay.AVW);
+        if (rc) return rc;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float *ws = (float *)workspace;
+    const int B = dims->batch, W = beam_width, BW = lay.B;
+    const int H = lay.H, Hp = lay.Hp, L = lay.L, V = lay.V;
+    const int top = top_tokens < V ? top_tokens : V;
+
+    SGLayout prep = lay;
+    prep.off_tokg = g.off_tokg;
+    for (int l = 0; l < L; ++l) {
+        prep.off_wpack[l] = g.off_wpack[l];
+        prep.off_bpack[l] = g.off_bpack[l];
+    }
+    rc = enqueue_prepare(prep, weights, ws, st);
+    if (rc) return rc;
+    float *wpack[PCM_MAX_LAYERS], *bpack[PCM_MAX_LAYERS];
+    for (int l = 0; l < L; ++l) {
+        wpack[l] = ws + g.off_wpack[l];
+        bpack[l] = ws + g.off_bpack[l];
+    }
+    // every slot starts from the same state (vae.py:446-453); the prime is
+    // run on all of them, which is what priming once and copying gives
+    if (Hp != H)
+        for (int s = 0; s < 2; ++s)
+            for (int l = 0; l < L; ++l)
+                pcm_launch_fill(ws + g.off_h[s][l], 0.f, (long long)BW * Hp, st);
+    for (int l = 0; l < L; ++l)
+        for (int k = 0; k < W; ++k) {
+            float *dst = ws + g.off_h[0][l] + (size_t)k * B * Hp;
+            if (h0)
+                pcm_launch_copy_rows(h0 + (long long)l * h0_layer_stride, H, dst,
+                                     Hp, B, H, st);
+            else
+                pcm_launch_fill(dst, 0.f, (long long)B * Hp, st);
+        }
+    if (lay.use_stack)
+        pcm_launch_fill(ws + g.off_S[0], 0.f, (long long)BW * lay.DW, st);
+    int64_t *cur_tok = (int64_t *)(ws + g.off_tok);
+    double *scores = (double *)(ws + bl.off_scores);
+    int32_t *hist_tok = (int32_t *)(ws + bl.off_hist_tok);
+    int32_t *hist_par = (int32_t *)(ws + bl.off_hist_par);
+
+    // slots: state copies still fed (the reference's zip() over tokens and
+    // states shrinks them when fewer beams than slots exist, vae.py:471-483);
+    // beams: entries of the beam list (search.py:186 zips them with the slots)
+    int slots = W, beams = 1, slot = 0;
+    const int total_steps = (prime_len - 1) + generate_len;
+    for (int s = 0; s < total_steps; ++s) {
+        const bool priming = s < prime_len - 1;
+        if (s < prime_len)
+            pcm_launch_broadcast_token(prime + s, BW, cur_tok, nullptr, 0, 0, st);
+        StepBufs sb;
+        memset(&sb, 0, sizeof(sb));
+        for (int l = 0; l < L; ++l) {
+            sb.h_prev[l] = ws + g.off_h[slot][l];
+            sb.h_new[l] = ws + g.off_h[slot ^ 1][l];
+        }
+        if (lay.use_stack) {
+            sb.S_prev = ws + g.off_S[slot];
+            sb.S_new = ws + g.off_S[slot ^ 1];
+            sb.av = ws + g.off_av;
+            sb.xtop = ws + g.off_xtop;
+        }
+        sb.tok = cur_tok;
+        rc = enqueue_step(lay, weights, ws + g.off_tokg, wpack, bpack, sb,
+                          nullptr, s, 0.f, 0, status, st,
+                          priming ? BW : slots * B);
+        if (rc) return rc;
+        slot ^= 1;
+        if (priming) continue;
+        const int gi = s - (prime_len - 1);
+        float *logits = ws + g.off_logits;   // [slots * B, V]
+        rc = pcm_linear_forward(ws + g.off_h[slot][L - 1], Hp, out_w, out_b,
+                                logits, V, slots * B, V, H, st);
+        if (rc) return rc;
+        BeamStepArgs a;
+        a.logits = logits; a.scores = scores;
+        a.hist_tok = hist_tok; a.hist_parent = hist_par; a.next_tok = cur_tok;
+        a.B = B; a.V = V; a.width = W;
+        a.used = slots < beams ? slots : beams;
+        a.top = top;
+        a.nb_next = a.used * top < W ? a.used * top : W;
+        a.slots_next = slots < a.nb_next ? slots : a.nb_next;
+        a.step = gi; a.temperature = temperature;
+        rc = pcm_launch_beam_step(a, st);
+        if (rc) return rc;
+        beams = a.nb_next;
+        slots = a.slots_next;
+    }
+    pcm_launch_beam_backtrack(hist_tok, hist_par, scores, B, W, beams,
+                              generate_len, tokens_out, beam_tokens_out,
+                              beam_scores_out, st);
+    return pcm_check_launch("stackgru_generate_beam");
+}
+
+}  // extern "C"

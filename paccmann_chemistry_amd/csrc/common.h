@@ -125,6 +125,28 @@ static inline void pcm_probe_end(int id, int layer = -1) {
             hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__); \
     } while (0)
 
+// ---- beam search step (head.hip) -------------------------------------------------
+struct BeamStepArgs {
+    const float *logits;   // [slots][B][V]: row k * B + b
+    double *scores;        // [B][width] running scores, in / out
+    int32_t *hist_tok;     // [G][B][width] token of each surviving beam
+    int32_t *hist_parent;  // [G][B][width] slot its sequence continues
+    int64_t *next_tok;     // [width * B] next input token of slot k: k * B + b
+    int B, V, width;
+    int used;        // beams expanded at this step (<= slots, <= beams alive)
+    int top;         // top tokens kept per beam (<= V)
+    int nb_next;     // beams alive after the step = min(width, used * top)
+    int slots_next;  // state slots fed at the next step
+    int step;
+    float temperature;
+};
+int pcm_launch_beam_step(const BeamStepArgs &a, hipStream_t stream);
+int pcm_launch_beam_backtrack(const int32_t *hist_tok,
+                              const int32_t *hist_parent, const double *scores,
+                              int B, int width, int nb, int G, int64_t *best_out,
+                              int64_t *beams_out, double *scores_out,
+                              hipStream_t stream);
+
 // ---- device helpers -------------------------------------------------------------
 // n / d for 0 <= n < 2^20 through a float reciprocal (3 VALU instead of ~35):
 // n + 0.5 is never within 0.5 of a multiple of d, far above fp32 rounding.

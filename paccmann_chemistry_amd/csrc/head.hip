@@ -382,6 +382,141 @@ int pcm_launch_broadcast_token(const int64_t *src, int B, int64_t *next_tok,
     return 0;
 }
 
+// ------------------------------------------------------------------------------
+// BeamSearch.step on the device (utils/search.py:169-201, 247-275)
+// ------------------------------------------------------------------------------
+// One block per batch row, one wave per state slot in use.  Wave k takes
+// softmax(logits[k][b] / T) (search.py:262), its `top` most probable tokens in
+// descending order (np.argsort(-p)[:top], search.py:189) and scores them as
+// score_k + log(p + eps) -- p + eps in fp32 as the reference's tensor
+// arithmetic does, the logarithm and the running score in double like its
+// Python floats (search.py:193).  Wave 0 then keeps the nb_next best
+// candidates in (score descending, candidate order) -- Python's stable
+// sorted(..., reverse=True)[:beam_width] (search.py:197-201) -- and records
+// token and parent slot of each survivor; the sequences themselves are
+// rebuilt once at the end (beam_backtrack_kernel).  Like the reference the
+// recurrent state of a slot is NOT moved to follow its beam's parent
+// (vae.py:471-483: hidden / stack stay with their slot).
+__global__ __launch_bounds__(1024) void beam_step_kernel(BeamStepArgs a) {
+    extern __shared__ __attribute__((aligned(8))) unsigned char beam_sm[];
+    const int ncand = a.used * a.top;
+    double *cscore = (double *)beam_sm;                   // [ncand]
+    int *ctok = (int *)(cscore + ncand);                  // [ncand]
+    float *prob = (float *)(ctok + ncand);                // [used][V]
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int k = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (k < a.used) {
+        const float *x = a.logits + ((long long)k * a.B + b) * a.V;
+        float *pr = prob + (long long)k * a.V;
+        float m = -INFINITY;
+        for (int v = lane; v < a.V; v += 64) m = fmaxf(m, x[v] / a.temperature);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+            m = fmaxf(m, __shfl_xor(m, off, 64));
+        float sum = 0.f;
+        for (int v = lane; v < a.V; v += 64) {
+            const float e = expf(x[v] / a.temperature - m);
+            pr[v] = e;
+            sum += e;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        for (int v = lane; v < a.V; v += 64) pr[v] = pr[v] / sum;
+        const double base = a.step == 0 ? 0.0 : a.scores[(long long)b * a.width + k];
+        for (int r = 0; r < a.top; ++r) {
+            // most probable token not taken yet; the lowest index wins a tie
+            float best = -1.f;
+            int bi = 0x7fffffff;
+            for (int v = lane; v < a.V; v += 64)
+                if (pr[v] > best) { best = pr[v]; bi = v; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float ob = __shfl_xor(best, off, 64);
+                const int oi = __shfl_xor(bi, off, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (lane == 0) {
+                const float q = best + 2.220446049250313e-16f;
+                cscore[k * a.top + r] = base + log((double)q);
+                ctok[k * a.top + r] = bi;
+            }
+            if ((bi & 63) == lane) pr[bi] = -1.f;   // taken
+        }
+    }
+    __syncthreads();
+    if (k != 0) return;
+    for (int j = 0; j < a.nb_next; ++j) {
+        double best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = lane; c < ncand; c += 64) {
+            const double sc = cscore[c];
+            if (sc > best) { best = sc; bi = c; }   // first maximum of the lane
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ob = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) {
+            const long long at = ((long long)a.step * a.B + b) * a.width + j;
+            a.scores[(long long)b * a.width + j] = best;
+            a.hist_tok[at] = ctok[bi];
+            a.hist_parent[at] = bi / a.top;
+            if (j < a.slots_next) a.next_tok[(long long)j * a.B + b] = ctok[bi];
+        }
+        if ((bi & 63) == lane) cscore[bi] = -INFINITY;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Rebuild every beam's token sequence from the per-step (token, parent slot)
+// records; beams past `nb` (fewer candidates than beam_width) are filled with -1.
+__global__ __launch_bounds__(256) void beam_backtrack_kernel(
+    const int32_t *hist_tok, const int32_t *hist_parent, const double *scores,
+    int B, int width, int nb, int G, int64_t *best_out, int64_t *beams_out,
+    double *scores_out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * width) return;
+    const int b = idx / width, j = idx - b * width;
+    if (scores_out)
+        scores_out[idx] = j < nb ? scores[idx] : -INFINITY;
+    int slot = j;
+    for (int t = G - 1; t >= 0; --t) {
+        long long tok = -1;
+        if (j < nb) {
+            const long long at = ((long long)t * B + b) * width + slot;
+            tok = hist_tok[at];
+            slot = hist_parent[at];
+        }
+        if (beams_out) beams_out[((long long)b * width + j) * G + t] = tok;
+        if (j == 0 && best_out) best_out[(long long)b * G + t] = tok;
+    }
+}
+
+int pcm_launch_beam_step(const BeamStepArgs &a, hipStream_t stream) {
+    const size_t lds = (size_t)a.used * a.top * (sizeof(double) + sizeof(int)) +
+                       (size_t)a.used * a.V * sizeof(float);
+    PCM_REQUIRE(a.used >= 1 && a.used <= 16 && lds <= 64 * 1024, PCM_EINVAL,
+                "beam step: %d slots x %d top tokens x vocab %d exceed the "
+                "kernel's limits (16 slots, 64 KiB LDS)", a.used, a.top, a.V);
+    hipLaunchKernelGGL(beam_step_kernel, dim3(a.B), dim3(64 * a.used), lds,
+                       stream, a);
+    return 0;
+}
+
+int pcm_launch_beam_backtrack(const int32_t *hist_tok,
+                              const int32_t *hist_parent, const double *scores,
+                              int B, int width, int nb, int G, int64_t *best_out,
+                              int64_t *beams_out, double *scores_out,
+                              hipStream_t stream) {
+    hipLaunchKernelGGL(beam_backtrack_kernel, dim3((B * width + 255) / 256),
+                       dim3(256), 0, stream, hist_tok, hist_parent, scores, B,
+                       width, nb, G, best_out, beams_out, scores_out);
+    return 0;
+}
+
 // encoder / decoder / target sequences of one batch (see pcm_prepare_batch)
 __global__ __launch_bounds__(256) void prepare_batch_kernel(
     const int64_t *flat, const int64_t *offsets, int B, int T,
@@ -501,6 +636,21 @@ int pcm_softmax_ce_static(const float *logits, const int64_t *targets,
     return softmax_ce_enqueue(logits, targets, lengths, step_weight, steps, batch,
                               vocab, loss, argmax, dlogits, scratch, status,
                               (hipStream_t)stream);
+}
+
+int pcm_search_step(const float *logits, int64_t rows, int32_t vocab,
+                    int32_t search, float temperature, uint64_t seed,
+                    int32_t step, int64_t *tokens_out, void *stream) {
+    PCM_REQUIRE(logits && tokens_out && rows > 0 && vocab > 0, PCM_EINVAL,
+                "search_step: bad args");
+    PCM_REQUIRE(rows < (1ll << 31), PCM_EINVAL, "search_step: too many rows");
+    PCM_REQUIRE(search == PCM_SEARCH_GREEDY || search == PCM_SEARCH_SAMPLING,
+                PCM_EINVAL, "search_step: unknown search %d", search);
+    PCM_REQUIRE(search != PCM_SEARCH_SAMPLING || temperature > 0.f, PCM_EINVAL,
+                "search_step: temperature must be positive");
+    pcm_launch_choose(logits, (int)rows, vocab, search, temperature, seed, step,
+                      tokens_out, tokens_out, 1, 0, (hipStream_t)stream);
+    return pcm_check_launch("search_step");
 }
 
 int pcm_reparam_forward(const float *mu, const float *logvar, const float *eps,

@@ -7,7 +7,10 @@ sharded path needs.  Loss scaling: the decoder loss is a MEAN over the local
 batch (vae.py:343) while the KL term is a SUM over the batch
 (loss_functions.py:39).  To reproduce the single-process gradient of the
 global batch, each rank back-propagates ``decoder_loss / world + kl_w * KL``
-and the gradients are SUM-reduced.
+and the gradients are SUM-reduced.  In packed mode (and for unequal shards)
+the divisor of step t is the number of rows active over ALL ranks:
+``global_step_weights`` all-reduces the T counts and the decoder head scales
+its row losses by them (``StackGRUDecoder.global_batch_loss``).
 
 Gradients travel as two flat fp32 buckets, decoder first: the decoder's
 gradients are final before the encoder's backward starts, so its all-reduce
@@ -23,10 +26,52 @@ def world():
     return 1, 0
 
 
-def scale_losses(decoder_loss, kl_div, kl_w):
-    """Per-rank scalar to back-propagate (see module docstring)."""
+def scale_losses(decoder_loss, kl_div, kl_w, global_share=False):
+    """Per-rank scalar to back-propagate (see module docstring).
+
+    global_share: the decoder loss already is this rank's share of the global
+    batch's loss (``StackGRUDecoder.global_batch_loss = True``: every step is
+    divided by the rows active over ALL ranks), so it is not divided again.
+    That form is exact for packed batches and unequal shards too; the plain
+    ``/ world`` form only for padded batches with equal shards."""
+    if global_share:
+        return decoder_loss + kl_w * kl_div
     size, _ = world()
     return decoder_loss / size + kl_w * kl_div
+
+
+def global_step_weights(lengths, steps, batch, device=None):
+    """fp32[T]: 1 / (rows active at step t over ALL ranks) -- the divisor of the
+    reference's per-step cross-entropy mean (vae.py:343 padded, vae.py:386
+    packed: the mean runs over the rows of the whole batch that are still
+    active), when the batch is sharded over ranks.  One all-reduce of T counts
+    per step; a single process gets 1 / local counts.
+
+    lengths: per-row lengths of THIS rank's shard (None = padded mode, every
+    row runs ``steps`` steps)."""
+    if lengths is None:
+        counts = torch.full((steps, ), int(batch), dtype=torch.int64)
+    else:
+        lens = torch.as_tensor(lengths).to('cpu', torch.int64).view(1, -1)
+        counts = (lens > torch.arange(steps).view(-1, 1)).sum(dim=1)
+    size, _ = world()
+    if size > 1:
+        # shards may differ in their longest sequence: count over the longest
+        # T of any rank (slot 0 carries T itself, reduced with MAX first)
+        on = 'cpu'
+        if dist.get_backend() == 'nccl':
+            on = device if device is not None else 'cuda'
+        longest = torch.tensor([steps], dtype=torch.int64, device=on)
+        dist.all_reduce(longest, op=dist.ReduceOp.MAX)
+        padded = torch.zeros(int(longest.item()), dtype=torch.int64, device=on)
+        padded[:steps] = counts.to(on)
+        dist.all_reduce(padded, op=dist.ReduceOp.SUM)
+        counts = padded[:steps]
+    weights = torch.where(
+        counts > 0, 1.0 / counts.clamp(min=1).to(torch.float32),
+        torch.zeros(steps, dtype=torch.float32, device=counts.device)
+    )
+    return weights if device is None else weights.to(device)
 
 
 class GradientBuckets:
@@ -156,12 +201,46 @@ class FlatAdam:
     def zero_grad(self):
         self.buckets.zero_grad()
 
+    def state_dict(self):
+        """Step count and moments per bucket (checkpoint / resume)."""
+        return {
+            'step_count': self.step_count, 'lr': self.lr,
+            'betas': tuple(self.betas), 'eps': self.eps,
+            'buckets': [
+                None if st is None else {
+                    'exp_avg': st['exp_avg'].clone(),
+                    'exp_avg_sq': st['exp_avg_sq'].clone(),
+                } for st in self.state
+            ],
+        }
+
+    def load_state_dict(self, state):
+        if len(state['buckets']) != len(self.state):
+            raise ValueError('FlatAdam: bucket count mismatch')
+        for st, saved in zip(self.state, state['buckets']):
+            if (st is None) != (saved is None):
+                raise ValueError('FlatAdam: bucket layout mismatch')
+            if st is None:
+                continue
+            for key in ('exp_avg', 'exp_avg_sq'):
+                if saved[key].numel() != st[key].numel():
+                    raise ValueError(f'FlatAdam: {key} size mismatch')
+                st[key].copy_(saved[key])
+        self.step_count = int(state['step_count'])
+        self.lr, self.eps = state['lr'], state['eps']
+        self.betas = tuple(state['betas'])
+
     def step(self):
         from .ops import adam_step
         self.step_count += 1
         for bucket, st in zip(self.buckets.buckets, self.state):
             if bucket is None:
                 continue
+            if bucket['ready'] >= 0:
+                # not reduced through GradientBuckets.finish() (a plain
+                # single-process loop such as train_vae): make sure every
+                # gradient sits in the flat buffer
+                self.buckets._gather_flat(bucket)
             adam_step(st['param'], bucket['flat'], st['exp_avg'],
                       st['exp_avg_sq'], self.lr, self.betas[0], self.betas[1],
                       self.eps, self.step_count)

@@ -481,6 +481,71 @@ def stackgru_generate(
     return tokens, logits
 
 
+def stackgru_generate_beam(
+    dims, weights, out_w, out_b, h0, prime, generate_len, beam_width,
+    top_tokens, temperature, want_beams=False, status=None
+):
+    """pcm_stackgru_generate_beam; h0 is [B,H] (broadcast) or [L,B,H].
+    Returns tokens i64[B, G] (the best beam of every row, without the prime),
+    and with ``want_beams`` also (beam tokens i64[B, width, G], scores
+    f64[B, width])."""
+    lib = load()
+    require_device(h0, 'generate h0')
+    dev = h0.device
+    n_layers, batch, hid = dims.layers, dims.batch, dims.hidden
+    weights = [None if w is None else _f32(w, 'weight').contiguous()
+               for w in weights]
+    wstruct = _lib.make_params(weights, n_layers)
+    h0 = _f32(h0, 'h0').contiguous()
+    h0_stride = 0 if h0.dim() == 2 else batch * hid
+    prime = prime.to(device=dev, dtype=torch.int64).contiguous().view(-1)
+    tokens = torch.empty(batch, generate_len, dtype=torch.int64, device=dev)
+    beams = scores = None
+    if want_beams:
+        beams = torch.empty(batch, beam_width, generate_len,
+                            dtype=torch.int64, device=dev)
+        scores = torch.empty(batch, beam_width, dtype=torch.float64,
+                             device=dev)
+    nbytes = lib.pcm_generate_beam_workspace_bytes(
+        ctypes.byref(dims), int(beam_width), int(generate_len)
+    )
+    if nbytes == 0:
+        check(-1, 'pcm_generate_beam_workspace_bytes')
+    work = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    out_w = _f32(out_w, 'output_layer.weight').contiguous()
+    out_b = _f32(out_b, 'output_layer.bias').contiguous()
+    check(
+        lib.pcm_stackgru_generate_beam(
+            ctypes.byref(dims), ctypes.byref(wstruct), ptr(out_w), ptr(out_b),
+            ptr(h0), h0_stride, ptr(prime), prime.numel(), int(generate_len),
+            int(beam_width), int(top_tokens), float(temperature), ptr(tokens),
+            ptr(beams), ptr(scores), ptr(work), nbytes, ptr(status),
+            stream_ptr(dev)
+        ), 'pcm_stackgru_generate_beam'
+    )
+    if want_beams:
+        return tokens, beams, scores
+    return tokens
+
+
+def search_step(logits, search, temperature=1.0, seed=0, step=0):
+    """pcm_search_step: one token per row of ``logits[..., V]`` (a GPU
+    tensor); returns i64 of shape ``logits.shape[:-1]``."""
+    lib = load()
+    require_device(logits, 'search logits')
+    x2, rows, ld = _rows2d(_f32(logits, 'search logits'), 'search logits')
+    if ld != x2.shape[1]:
+        x2 = x2.contiguous()
+    out = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    check(
+        lib.pcm_search_step(
+            ptr(x2), rows, x2.shape[1], int(search), float(temperature),
+            int(seed), int(step), ptr(out), stream_ptr(logits.device)
+        ), 'pcm_search_step'
+    )
+    return out.view(logits.shape[:-1])
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step,
               grad_scale=1.0):
     """In-place torch.optim.Adam update of a flat fp32 buffer."""

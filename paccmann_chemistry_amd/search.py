@@ -1,11 +1,15 @@
 """Decoding strategies: mirror of the reference's ``utils/search.py`` classes.
 
-``StackGRUDecoder.generate_from_latent`` recognises ``GreedySearch`` and
-``SamplingSearch`` instances and runs their ``step`` inside the fused HIP
-generation loop (``pcm_stackgru_generate``); the methods below keep the
-reference's stand-alone API (shape / type checks, ``forward`` / ``step``).
-BeamSearch is CPU list processing in the reference (search.py:144-275) and
-outside the accelerated path; it is kept as a host-side restatement.
+``StackGRUDecoder.generate_from_latent`` recognises ``GreedySearch``,
+``SamplingSearch`` and ``BeamSearch`` instances and runs their ``step`` inside
+the fused HIP generation calls (``pcm_stackgru_generate``,
+``pcm_stackgru_generate_beam``).  The methods below keep the reference's
+stand-alone API (shape / type checks, ``forward`` / ``step``): greedy and
+sampling run ``pcm_search_step`` for logits that live on the GPU (one launch
+for the whole batch instead of the reference's per-row ``multinomial`` loop,
+search.py:117-122,136-141) and plain torch for CPU logits; ``BeamSearch``'s
+stand-alone methods are CPU list processing as in the reference
+(search.py:144-275).
 """
 from math import log
 from sys import float_info
@@ -45,15 +49,27 @@ class Search(nn.Module):
             )
 
 
+def _device_search(logits, mode, temperature=1.0, seed=None):
+    """pcm_search_step over every row of GPU logits[..., V]."""
+    from .ops import search_step
+    if mode == 1 and seed is None:
+        seed = int(torch.randint(0, 2**62, (1, )).item())
+    return search_step(logits.detach(), mode, temperature, seed or 0)
+
+
 class GreedySearch(Search):
     """Greedy search (search.py:56-87): first maximum wins on ties."""
 
     def forward(self, logits: torch.Tensor) -> torch.Tensor:
         super().forward(logits)
+        if logits.is_cuda:
+            return _device_search(logits, 0)
         return torch.argmax(logits, 2)
 
     def step(self, logits: torch.Tensor) -> torch.Tensor:
         super().step(logits)
+        if logits.is_cuda and logits.dim() == 2:
+            return _device_search(logits, 0).unsqueeze(1)
         return torch.argmax(logits, 1, keepdim=True)
 
 
@@ -64,21 +80,30 @@ class SamplingSearch(Search):
         super().__init__(*args, **kwargs)
         self.temperature = temperature
 
-    def forward(self, logits: torch.Tensor) -> torch.Tensor:
+    def forward(self, logits: torch.Tensor, seed=None) -> torch.Tensor:
         super().forward(logits)
+        if logits.is_cuda:
+            # every (row, position) in one launch: the batched multinomial
+            return _device_search(logits, 1, self.temperature, seed).squeeze()
         probabilities = torch.softmax(logits.div(self.temperature), 2)
         batch, length, vocab = probabilities.shape
         draws = torch.multinomial(probabilities.reshape(-1, vocab), 1)
         return draws.view(batch, length, 1).squeeze()
 
-    def step(self, logits: torch.Tensor) -> torch.Tensor:
+    def step(self, logits: torch.Tensor, seed=None) -> torch.Tensor:
         super().step(logits)
+        if logits.is_cuda and logits.dim() == 2:
+            return _device_search(
+                logits, 1, self.temperature, seed
+            ).unsqueeze(1)
         probabilities = torch.softmax(logits.div(self.temperature), 1)
         return torch.multinomial(probabilities, 1)
 
 
 class BeamSearch(Search):
-    """Beam search (search.py:144-275), host-side."""
+    """Beam search (search.py:144-275).  ``generate_from_latent`` runs it on
+    the device (pcm_stackgru_generate_beam); the stand-alone ``forward`` /
+    ``step`` below are the reference's CPU list processing."""
 
     def __init__(self, beam_width: int = 3, temperature: float = 1.0,
                  top_tokens: int = 5):

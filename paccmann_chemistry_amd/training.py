@@ -179,8 +179,9 @@ def train_vae(
             decoder_loss, mu, logvar, kl_growth=kl_growth, step=global_step
         )
         loss.backward()
-        train_loss += loss.detach().item()
-        vae_model.check_tokens()
+        # the per-step sync of training.py:154, with the bad-token status of
+        # the whole model folded into the same device->host read
+        train_loss += vae_model.loss_item(loss)
         optimizer.step()
 
         if _iter and _iter % log_interval == 0:

@@ -77,6 +77,46 @@ def packed_sequential_data_preparation(
     return [pack_sequence(entry) for entry in (enc, dec, tgt)]
 
 
+class _PinnedStaging:
+    """Two reusable page-locked host buffers per device, used alternately: a
+    batch's tokens, offsets and step bases are gathered into one of them and
+    copied to the device with ONE truly asynchronous host->device copy (from
+    pageable memory ``non_blocking=True`` is a synchronous staged copy).  A
+    buffer is only refilled after the copy that last read it has finished (an
+    event recorded behind the copy), so batch k+1 can be staged while batch
+    k's copy and kernels are still in flight."""
+
+    def __init__(self):
+        self.slots = [[None, None], [None, None]]   # [buffer, copy event]
+        self.turn = 0
+
+    def stage(self, parts, device):
+        need = sum(int(p.numel()) for p in parts)
+        slot = self.slots[self.turn]
+        self.turn ^= 1
+        if slot[1] is not None:
+            slot[1].synchronize()
+        if slot[0] is None or slot[0].numel() < need:
+            slot[0] = torch.empty(max(need, 1 << 16), dtype=torch.int64,
+                                  pin_memory=True)
+        host = slot[0][:need]
+        torch.cat(parts, out=host)
+        staged = host.to(device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(device))
+        return staged
+
+
+_staging = {}
+
+
+def _stage_to_device(parts, device):
+    key = torch.device(device).index or 0
+    if key not in _staging:
+        _staging[key] = _PinnedStaging()
+    return _staging[key].stage(parts, device)
+
+
 def prepare_batch_on_device(
     batch, packed, input_keep=1, dropout_index=1, device=None, keep_mask=None,
     seed=None
@@ -122,7 +162,7 @@ def prepare_batch_on_device(
             )
         batch_sizes = (lens.view(1, -1) > torch.arange(steps).view(-1, 1)).sum(1)
         parts.append(torch.cumsum(batch_sizes, 0) - batch_sizes)
-    staged = torch.cat(parts).to(device, non_blocking=True)
+    staged = _stage_to_device(parts, device)
     total = int(offsets[-1])
     flat, offs = staged[:total], staged[total:total + n_batch + 1]
     base = staged[total + n_batch + 1:] if packed else None
@@ -238,17 +278,35 @@ def crop_start(smiles, smiles_language):
 
 def packed_to_padded(seq, target_packed=None):
     """utils/utils.py:171-203: per-step outputs of a packed run (``seq[t]``
-    holds one token per sequence still active at step t) -> f32[B, T] padded
-    with 0.  The reference derives the finished rows from STOP tokens in the
-    packed target; with the length-sorted layout its loops assume, the active
-    rows of step t are simply the first ``len(seq[t])`` ones, which is what is
-    used here (``target_packed`` is accepted for signature compatibility)."""
+    holds one value per sequence still active at step t) -> f32[B, T] padded
+    with 0.  Like the reference, the rows that have ended are derived from the
+    STOP tokens (3) of the packed target: a row whose target at step t-1 was
+    STOP is absent from step t+1 on.  Without ``target_packed`` the active rows
+    of step t are the first ``len(seq[t])`` ones (the length-sorted layout)."""
     steps = len(seq)
     batch_size = len(seq[0])
     padded = torch.zeros(batch_size, steps)
+    ended = torch.zeros(batch_size, dtype=torch.bool)
+    if target_packed is not None and len(target_packed) == 0:
+        target_packed = None
     for t in range(steps):
-        row = torch.as_tensor(seq[t]).reshape(-1)
-        padded[:row.numel(), t] = row.to(padded.dtype)
+        row = torch.as_tensor(seq[t]).reshape(-1).to(padded.dtype)
+        if target_packed is None:
+            padded[:row.numel(), t] = row
+            continue
+        alive = (~ended).nonzero().view(-1)
+        if alive.numel() != row.numel():
+            raise ValueError(
+                f'step {t}: {row.numel()} outputs for {alive.numel()} '
+                'sequences without a STOP target so far'
+            )
+        padded[alive, t] = row
+        if t > 0:
+            prev = torch.as_tensor(target_packed[t - 1]).reshape(-1)
+            # positions in the step's own (shrunken) list -> batch rows
+            # (rows alive at t-1, two steps behind the STOP as in the reference)
+            ended[alive_prev[(prev == 3).nonzero().view(-1)]] = True
+        alive_prev = alive
     return padded
 
 

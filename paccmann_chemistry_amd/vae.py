@@ -12,7 +12,8 @@ from torch.nn.utils.rnn import PackedSequence
 from . import _lib
 from .hyperparams import OPTIMIZER_FACTORY
 from .ops import (
-    DecoderHeadFn, ReparamFn, check_status, linear, stackgru_generate
+    DecoderHeadFn, ReparamFn, check_status, linear, stackgru_generate,
+    stackgru_generate_beam
 )
 from .search import BeamSearch, GreedySearch, SamplingSearch
 from .stack_rnn import StackGRU
@@ -128,6 +129,10 @@ class StackGRUDecoder(StackGRU):
         ](self.parameters(), lr=params.get('lr', 0.01))  # yapf: disable
         self.outputs = None
         self.logits = None
+        # data parallel: divide every step's cross entropy by the rows active
+        # over ALL ranks, so that the ranks' losses (and gradients) sum to the
+        # single-process loss of the global batch (dp.global_step_weights)
+        self.global_batch_loss = False
 
     def _latent_to_hidden(self, latent_z):
         """vae.py:316 / 425-427.  A latent repeated over the layer axis
@@ -164,9 +169,15 @@ class StackGRUDecoder(StackGRU):
         if stack is self.init_stack:
             stack = None
         out, _, _ = self._run_sequence(tokens, lengths, hidden, stack)
+        step_weight = None
+        if self.global_batch_loss:
+            from . import dp
+            step_weight = dp.global_step_weights(
+                lengths, tokens.shape[0], tokens.shape[1], out.device
+            )
         loss, argmax, logits = DecoderHeadFn.apply(
             out, self.output_layer.weight, self.output_layer.bias, targets,
-            lengths, self._status_word(out.device)
+            lengths, self._status_word(out.device), step_weight
         )
         # For monitoring purposes (vae.py:346-348; packed: float tensor with
         # zeros where a sequence has ended, utils/utils.py:171-203)
@@ -179,8 +190,9 @@ class StackGRUDecoder(StackGRU):
         generate_len=100, seed=None, return_logits=False
     ):
         """vae.py:391-489.  latent_z [1,B,Z]; prime_input i64[P]; returns
-        i64[B, P+generate_len] (the prime included).  Greedy and sampling run
-        in one fused generation call; beam search steps the cell from Python.
+        i64[B, P+generate_len] (the prime included).  Greedy, sampling and
+        beam search (which returns i64[B, generate_len], the best beam without
+        the prime, vae.py:485-488) each run in one fused generation call.
         """
         if isinstance(search, type):
             search = search()
@@ -219,41 +231,23 @@ class StackGRUDecoder(StackGRU):
             return tokens, logits
         return tokens
 
-    def _generate_beam(self, latent_z, prime_input, search, generate_len):
-        """Beam branch of vae.py:439-488, stepping the fused cell per token."""
+    def _generate_beam(self, latent_z, prime_input, search, generate_len,
+                       return_beams=False):
+        """Beam branch of vae.py:439-488 in one fused call: the beam_width
+        state copies run as one batch, BeamSearch.step (search.py:247-275) is
+        a device kernel.  Returns i64[B, generate_len] -- the best-scoring
+        sequence per row, without the prime, as the reference does."""
         batch_size = latent_z.shape[1]
-        device = latent_z.device
         with torch.no_grad():
             hidden = self._latent_to_hidden(latent_z)
-            hidden = hidden.unsqueeze(0).repeat(self.n_layers, 1, 1)
-            stack = self.init_stack.to(device)
-            prime = prime_input.view(-1).to(device)
-            for token in prime[:-1]:
-                _, hidden, stack = self(
-                    token.repeat(1, batch_size), hidden, stack
-                )
-            input_token = prime[-1].repeat(1, batch_size)
-            beams = [[[list(), 0.0]]] * batch_size
-            width = search.beam_width
-            input_token = torch.stack([input_token.clone() for _ in range(width)])
-            hidden = torch.stack([hidden.clone() for _ in range(width)])
-            stack = torch.stack([stack.clone() for _ in range(width)])
-            for _ in range(generate_len):
-                outs, hids, stacks = zip(*[
-                    self(tok, hid, stk)
-                    for tok, hid, stk in zip(input_token, hidden, stack)
-                ])
-                logits = torch.stack([
-                    linear(o, self.output_layer.weight,
-                           self.output_layer.bias).squeeze(0) for o in outs
-                ])
-                hidden = torch.stack(hids)
-                stack = torch.stack(stacks)
-                input_token, beams = search.step(logits.detach().cpu(), beams)
-                input_token = input_token.to(device).unsqueeze(1)
-        return torch.stack([
-            torch.tensor([int(t) for t in beam[0][0]]) for beam in beams
-        ])
+            return stackgru_generate_beam(
+                self._dims(batch_size), self._weights(),
+                self.output_layer.weight, self.output_layer.bias, hidden,
+                prime_input.view(-1), generate_len, search.beam_width,
+                search.top_tokens, search.temperature,
+                want_beams=return_beams,
+                status=self._status_word(hidden.device)
+            )
 
 
 class TeacherVAE(nn.Module):
@@ -264,8 +258,25 @@ class TeacherVAE(nn.Module):
         self.encoder = encoder
         self.decoder = decoder
 
+    def _stackgrus(self):
+        mods = [self.encoder, self.decoder]
+        if getattr(self.encoder, 'bidirectional', False):
+            mods.append(self.encoder.backward_stackgru)
+        return mods
+
+    def _share_status(self, device):
+        """One int32 status word for every StackGRU of this model, so a step
+        needs a single device->host read to learn about bad token ids."""
+        word = self.encoder._status_word(device)
+        for mod in self._stackgrus():
+            mod._status = word
+        return word
+
     def encode(self, input_seq):
         """vae.py:506-522."""
+        data = getattr(input_seq, 'data', input_seq)
+        if isinstance(data, torch.Tensor) and data.is_cuda:
+            self._share_status(data.device)
         mu, logvar = self.encoder.encoder_train_step(input_seq)
         return mu, logvar
 
@@ -279,6 +290,8 @@ class TeacherVAE(nn.Module):
     def decode(self, latent_z, input_seq, target_seq):
         """vae.py:542-569.  The reference repeats the latent over the layer
         axis; the kernel broadcasts one projected [B,H] instead."""
+        if latent_z.is_cuda:
+            self._share_status(latent_z.device)
         if latent_z.dim() == 2:
             latent_z = latent_z.unsqueeze(0)
         latent_z = latent_z.expand(self.decoder.n_layers, -1, -1) \
@@ -294,9 +307,34 @@ class TeacherVAE(nn.Module):
 
     def check_tokens(self):
         """Raise RuntimeError if any forward since the last check saw a token
-        id outside the vocabulary (one device->host read per module)."""
-        self.encoder.check_tokens()
-        self.decoder.check_tokens()
+        id outside the vocabulary (one device->host read: the modules share
+        their status word)."""
+        seen = set()
+        for mod in self._stackgrus():
+            if mod._status is not None and id(mod._status) not in seen:
+                seen.add(id(mod._status))
+                check_status(mod._status)
+
+    def loss_item(self, loss):
+        """``loss.item()`` and ``check_tokens()`` in ONE device->host read (the
+        per-step sync point of training.py:154): returns the loss as a float,
+        raises RuntimeError for out-of-vocabulary token ids."""
+        words = [m._status for m in self._stackgrus() if m._status is not None]
+        if not words or not loss.is_cuda:
+            self.check_tokens()
+            return loss.detach().item()
+        flags = words[0]
+        for other in words[1:]:
+            if other is not flags:
+                flags = flags | other
+        value, status = torch.cat(
+            [loss.detach().reshape(1).double(), flags.double()]
+        ).tolist()
+        if int(status) & _lib.STATUS_BAD_TOKEN:
+            for word in words:
+                word.zero_()
+            raise RuntimeError('index out of range in self (token ids)')
+        return value
 
     def generate(
         self, latent_z, prime_input, end_token, generate_len=100,

@@ -102,6 +102,103 @@ def _worker(rank, port, overlap, out_dir):
         dist.destroy_process_group()
 
 
+RAGGED_LENGTHS = [6, 5, 5, 3, 2, 2]   # global batch, sorted (pack_sequence)
+SHARDS = [[0, 1, 2, 3], [4, 5]]        # unequal shards on purpose
+
+
+def _ragged_inputs():
+    from oracle import weights as W
+    tokens = W.synthetic_tokens(STEPS, P['batch_size'], P['vocab_size'], 5,
+                                RAGGED_LENGTHS)
+    targets = W.shifted_targets(tokens)
+    for b, n in enumerate(RAGGED_LENGTHS):
+        targets[n - 1:, b] = 0
+    eps = torch.randn(P['batch_size'], P['latent_dim'],
+                      generator=torch.Generator().manual_seed(6))
+    return tokens, targets, eps, torch.tensor(RAGGED_LENGTHS)
+
+
+def _weighted_loss_parts(sd, tokens, targets, eps, lengths, weights):
+    """Packed-mode loss of one shard with the per-step divisors supplied:
+    sum_t weights[t] * sum_{b active at t} CE[t, b] (what pcm_softmax_ce
+    computes when it is handed step_weight)."""
+    from oracle import stackgru_oracle as O
+    enc, dec = O.sub_params(sd, 'encoder'), O.sub_params(sd, 'decoder')
+    mu, logvar = O.encoder_forward(enc, tokens, P['stack_depth'], lengths)
+    z = O.reparameterize(mu, logvar, eps)
+    _, logits, _ = O.decoder_forward(dec, z, tokens, targets,
+                                     P['stack_depth'], lengths)
+    nll = -torch.log_softmax(logits, -1).gather(
+        2, targets.unsqueeze(-1)).squeeze(-1)
+    active = (lengths.view(1, -1) >
+              torch.arange(tokens.shape[0]).view(-1, 1)).to(nll.dtype)
+    loss = ((nll * active).sum(dim=1) * weights).sum()
+    return loss, O.kl_divergence(mu, logvar)
+
+
+def _ragged_worker(rank, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+    try:
+        from oracle import weights as W
+        from paccmann_chemistry_amd import dp
+        model = _Holder(W.make_state_dict(P, 21))
+        buckets = dp.GradientBuckets(model, overlap=True)
+        tokens, targets, eps, lengths = _ragged_inputs()
+        rows = SHARDS[rank]
+        # each shard is trimmed to ITS longest sequence: the ranks disagree
+        # on the number of steps, as separately packed shards do
+        steps = int(lengths[rows].max())
+        weights = dp.global_step_weights(lengths[rows], steps, len(rows))
+        buckets.zero_grad()
+        dec_loss, kl = _weighted_loss_parts(
+            model.as_dict(), tokens[:steps, rows], targets[:steps, rows],
+            eps[rows], lengths[rows], weights)
+        dp.scale_losses(dec_loss, kl, KL_W, global_share=True).backward()
+        buckets.finish()
+        torch.save({
+            'grads': {k: p.grad.clone() for k, p in model.named_parameters()},
+            'weights': weights, 'loss': dec_loss.detach(),
+        }, os.path.join(out_dir, f'ragged{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_packed_mode_global_step_counts(tmp_path):
+    """Packed mode: step t's cross entropy is a mean over the rows active in
+    the WHOLE batch (vae.py:386).  With the batch sharded unevenly over two
+    ranks, dp.global_step_weights all-reduces the per-step counts and the
+    summed gradients equal the single-process gradient of the global batch."""
+    from oracle import stackgru_oracle as O
+    from oracle import weights as W
+    port = _free_port()
+    mp.spawn(_ragged_worker, args=(port, str(tmp_path)), nprocs=WORLD,
+             join=True)
+    sd = {k: v.clone().requires_grad_(True)
+          for k, v in W.make_state_dict(P, 21).items()}
+    tokens, targets, eps, lengths = _ragged_inputs()
+    dec_loss, mu, logvar, _, _ = O.vae_forward(
+        sd, tokens, tokens, targets, eps, P['stack_depth'], lengths)
+    (dec_loss + KL_W * O.kl_divergence(mu, logvar)).backward()
+    got = [torch.load(tmp_path / f'ragged{r}.pt') for r in range(WORLD)]
+    counts = (lengths.view(1, -1) > torch.arange(STEPS).view(-1, 1)).sum(1)
+    for r in range(WORLD):
+        steps = int(lengths[SHARDS[r]].max())
+        assert torch.equal(got[r]['weights'],
+                           (1.0 / counts[:steps].float()))
+    total = sum(g['loss'] for g in got)
+    assert abs(total.item() - dec_loss.item()) < 1e-5 * abs(dec_loss.item())
+    for key, ref in sd.items():
+        scale = ref.grad.abs().max().clamp(min=1e-9)
+        for r in range(WORLD):
+            err = ((got[r]['grads'][key] - ref.grad).abs().max() / scale).item()
+            assert err < 2e-5, (key, r, err)
+
+
 @pytest.mark.parametrize('overlap', [False, True])
 def test_gradient_allreduce_matches_global_batch(tmp_path, overlap):
     port = _free_port()
@@ -128,3 +225,8 @@ def test_single_process_is_identity():
     assert dp.world() == (1, 0)
     a, b = torch.tensor(2.0), torch.tensor(3.0)
     assert dp.scale_losses(a, b, 0.5).item() == 3.5
+    assert dp.scale_losses(a, b, 0.5, global_share=True).item() == 3.5
+    w = dp.global_step_weights(torch.tensor([3, 1]), 4, 2)
+    assert torch.equal(w, torch.tensor([0.5, 1.0, 1.0, 0.0]))
+    assert torch.equal(dp.global_step_weights(None, 2, 4),
+                       torch.tensor([0.25, 0.25]))

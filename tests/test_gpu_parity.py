@@ -626,6 +626,102 @@ def test_greedy_decode_matches_oracle(name):
     assert torch.equal(tokens.cpu(), r_tokens)
 
 
+@pytest.mark.parametrize('name', golden_names('beam_'))
+def test_beam_decode_golden(name):
+    """generate_from_latent(search=BeamSearch) on the device
+    (pcm_stackgru_generate_beam) against the reference's own beams
+    (vae.py:439-488, search.py:169-275): the returned best sequence, every
+    beam and every score (sums of double log-probabilities)."""
+    from paccmann_chemistry_amd import BeamSearch
+    g = Golden(name)
+    vae = _build_vae(dict(g.params), g.weights, train=False)
+    search = BeamSearch(beam_width=int(g.data['beam_width']),
+                        temperature=float(g.data['temperature']),
+                        top_tokens=int(g.data['top_tokens']))
+    z, prime = g.tensor('z').to(_dev()), g.tensor('prime').to(_dev())
+    best = vae.decoder.generate_from_latent(
+        z, prime, torch.tensor([3]), search=search,
+        generate_len=int(g.data['generate_len']))
+    assert np.array_equal(best.cpu().numpy(), g.data['tokens'])
+    vae.decoder._update_batch_size(z.shape[1])
+    tokens, beams, scores = vae.decoder._generate_beam(
+        z, prime, search, int(g.data['generate_len']), return_beams=True)
+    assert torch.equal(tokens, best)
+    assert np.array_equal(beams.cpu().numpy(), g.data['beam_tokens'])
+    assert np.allclose(scores.cpu().numpy(), g.data['beam_scores'],
+                       rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize('width,top', [(2, 5), (8, 3), (5, 30), (1, 1)])
+def test_beam_decode_matches_oracle(width, top):
+    """Beam shapes beyond the fixtures, against the oracle's beam branch:
+    more state copies than first-step candidates (8 x 3: the reference's zip()
+    drops copies), top_tokens above the vocabulary tile, a single beam, a
+    batch that is no tile multiple."""
+    from paccmann_chemistry_amd import BeamSearch
+    p = {
+        'latent_dim': 16, 'rnn_cell_size': 64, 'embedding_size': 37,
+        'vocab_size': 37, 'stack_width': 6, 'stack_depth': 5, 'n_layers': 2,
+        'dropout': 0.0, 'batch_size': 21, 'batch_mode': 'padded',
+        'embedding': 'one_hot', 'use_stack': True, 'bidirectional': False
+    }
+    sd = W.make_state_dict(p, 88, scale=0.35)
+    vae = _build_vae(p, sd, train=False)
+    z = torch.from_numpy(np.random.default_rng(89).standard_normal(
+        (21, 16)).astype(np.float32))
+    prime, gen_len = torch.tensor([2, 7]), 9
+    search = BeamSearch(beam_width=width, temperature=0.9, top_tokens=top)
+    vae.decoder._update_batch_size(21)
+    tokens, beams, scores = vae.decoder._generate_beam(
+        z.unsqueeze(0).to(_dev()), prime.to(_dev()), search, gen_len,
+        return_beams=True)
+    with torch.no_grad():
+        r_best, r_beams = O.generate_from_latent_beam(
+            O.sub_params(sd, 'decoder'), z, prime, gen_len, p['stack_depth'],
+            width, top, 0.9)
+    assert torch.equal(tokens.cpu(), r_best)
+    alive = len(r_beams[0])
+    want = np.array([[beam[0] for beam in row] for row in r_beams])
+    assert np.array_equal(beams.cpu().numpy()[:, :alive], want)
+    assert (beams.cpu().numpy()[:, alive:] == -1).all()
+    want_scores = np.array([[beam[1] for beam in row] for row in r_beams])
+    assert np.allclose(scores.cpu().numpy()[:, :alive], want_scores,
+                       rtol=2e-6, atol=0)
+
+
+def test_search_steps_on_device_logits():
+    """GreedySearch / SamplingSearch forward() and step() on GPU logits
+    (pcm_search_step: the batched form of the reference's per-row multinomial
+    loop, search.py:117-122,136-141): greedy equals argmax with the first
+    maximum on ties, sampling picks the inverse-CDF token of the regenerated
+    uniforms, both keep the reference's output shapes."""
+    import paccmann_chemistry_amd as P
+    from test_gpu_fullsize import _uniform
+    rng = np.random.default_rng(31)
+    logits = torch.from_numpy(
+        rng.standard_normal((6, 11, 23)).astype(np.float32) * 2)
+    logits[0, 0, 3] = logits[0, 0, 9] = 7.0          # a tie: index 3 wins
+    dev_logits = logits.to(_dev())
+    greedy = P.GreedySearch()
+    assert torch.equal(greedy(dev_logits).cpu(), torch.argmax(logits, 2))
+    assert greedy(dev_logits)[0, 0].item() == 3
+    step = greedy.step(dev_logits[:, 0])
+    assert step.shape == (6, 1)
+    assert torch.equal(step.cpu(), torch.argmax(logits[:, 0], 1, keepdim=True))
+    sampler = P.SamplingSearch(temperature=0.6)
+    draws = sampler.forward(dev_logits, seed=1234)
+    assert draws.shape == (6, 11)
+    u = _uniform(1234, np.arange(66, dtype=np.uint64)).astype(np.float64)
+    cum = torch.cumsum(torch.softmax(logits.double().view(66, 23) / 0.6, 1), 1)
+    want = (cum.numpy() > u[:, None]).argmax(axis=1)
+    assert np.array_equal(draws.cpu().numpy().reshape(-1), want)
+    one = sampler.step(dev_logits[:, 2], seed=77)
+    assert one.shape == (6, 1) and one.dtype == torch.int64
+    # CPU logits keep the reference's torch path
+    assert greedy.step(logits[:, 0]).shape == (6, 1)
+    assert sampler.step(logits[:, 0]).shape == (6, 1)
+
+
 def test_sampling_search_distribution():
     """SamplingSearch.step (search.py:124-141): device draws follow
     softmax(logits / T); checked through generation statistics."""
@@ -678,10 +774,12 @@ def test_cpu_tensor_fails_loudly():
         enc.cpu().encoder_train_step(g.tensor('tokens'))
 
 
-def test_bench_distributed_path_on_one_rank():
+@pytest.mark.parametrize('ragged', [False, True])
+def test_bench_distributed_path_on_one_rank(ragged):
     """bench.py's N > 1 code path (RCCL process group, gradient buckets reduced
-    asynchronously from autograd hooks, barriers, MAX over ranks) rehearsed in
-    a one-rank group on this GPU: same final loss as the plain run."""
+    asynchronously from autograd hooks, the all-reduced per-step row counts of
+    the decoder loss, barriers, MAX over ranks) rehearsed in a one-rank group
+    on this GPU: same final loss as the plain run, padded and ragged packed."""
     import json
     import os
     import subprocess
@@ -689,6 +787,8 @@ def test_bench_distributed_path_on_one_rank():
     from conftest import ROOT
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2',
            '--warmup', '1', '--batch', '64', '--no-cpu-baseline', '--probe', '0']
+    if ragged:
+        cmd.append('--ragged')
     losses = []
     for force in ('0', '1'):
         env = dict(os.environ, PCM_BENCH_FORCE_DIST=force,
@@ -702,6 +802,69 @@ def test_bench_distributed_path_on_one_rank():
         assert line['n_gpus'] == 1 and line['value'] > 0
         losses.append(line['final_loss'])
     assert losses[0] == losses[1]
+
+
+@pytest.mark.parametrize('mode', ['padded', 'packed'])
+def test_data_parallel_shards_sum_to_global_batch(mode, monkeypatch):
+    """Data-parallel loss scaling on the product path, without a second GPU:
+    the global batch once as a single process, then as two unequal shards whose
+    decoder heads get the GLOBAL per-step row counts (what
+    dp.global_step_weights all-reduces).  The shards' losses and gradients must
+    sum to the single-process ones (vae.py:343 / 386: the cross-entropy mean
+    runs over the rows of the whole batch active at each step)."""
+    from paccmann_chemistry_amd import dp, vae_loss_function
+    p = {
+        'latent_dim': 16, 'rnn_cell_size': 64, 'embedding_size': 20,
+        'vocab_size': 20, 'stack_width': 6, 'stack_depth': 5, 'n_layers': 2,
+        'dropout': 0.0, 'batch_size': 10, 'batch_mode': mode,
+        'embedding': 'one_hot', 'use_stack': True, 'bidirectional': False
+    }
+    steps, batch = 9, 10
+    lengths = [9, 9, 8, 6, 6, 5, 3, 3, 2, 2] if mode == 'packed' else None
+    shards = [list(range(0, 7)), list(range(7, 10))]
+    sd = W.make_state_dict(p, 610)
+    tokens = W.synthetic_tokens(steps, batch, 20, 611, lengths)
+    targets = W.shifted_targets(tokens)
+    if lengths is not None:
+        for b, n in enumerate(lengths):
+            targets[n - 1:, b] = 0
+    eps = torch.from_numpy(np.random.default_rng(612).standard_normal(
+        (batch, 16)).astype(np.float32))
+    dev = _dev()
+    pack = torch.nn.utils.rnn.pack_sequence
+
+    def run(rows, weights):
+        q = dict(p, batch_size=len(rows))
+        vae = _build_vae(q, sd)
+        vae.decoder.global_batch_loss = weights is not None
+        if weights is not None:
+            monkeypatch.setattr(
+                dp, 'global_step_weights',
+                lambda lens, t, b, device=None: weights[:t].to(device))
+        if lengths is None:
+            enc = tokens[:, rows].to(dev)
+            tgt = targets[:, rows].to(dev)
+        else:
+            enc = pack([tokens[:lengths[b], b].to(dev) for b in rows])
+            tgt = pack([targets[:lengths[b], b].to(dev) for b in rows])
+        dec_loss, mu, logvar = vae(enc, enc, tgt, eps=eps[rows].to(dev))
+        total, _ = vae_loss_function(dec_loss, mu, logvar, kl_growth=0.003,
+                                     step=5000)
+        total.backward()
+        grads = {k: q_.grad.detach().double().cpu()
+                 for k, q_ in vae.named_parameters() if q_.grad is not None}
+        return total.item(), grads
+
+    want_loss, want = run(list(range(batch)), None)
+    lens = torch.tensor(lengths if lengths else [steps] * batch)
+    counts = (lens.view(1, -1) > torch.arange(steps).view(-1, 1)).sum(1)
+    weights = 1.0 / counts.float()
+    parts = [run(rows, weights) for rows in shards]
+    got_loss = sum(part[0] for part in parts)
+    assert abs(got_loss - want_loss) < 1e-5 * abs(want_loss)
+    for key, ref in want.items():
+        got = sum(part[1][key] for part in parts)
+        assert _rel_to_max(got, ref) < 2e-5, key
 
 
 @pytest.mark.parametrize('packed', [False, True])
@@ -742,6 +905,31 @@ def test_prepare_batch_on_device_matches_host(packed):
                                                  dtype=padded.dtype)])
         for g, w in zip(got, (padded, dec, tgt)):
             assert torch.equal(g.cpu(), w)
+
+
+@pytest.mark.parametrize('name', ['prepare_padded', 'prepare_packed'])
+def test_prepare_batch_matches_reference_fixture(name):
+    """pcm_prepare_batch bit-exact against the REFERENCE's own output for the
+    same batch and the same Bernoulli draws (tests/golden/prepare_*.npz, made
+    by oracle/make_golden.py from utils/utils.py:29-146), staged through the
+    pinned host buffers; twice, so both staging buffers are used."""
+    import os
+    from conftest import GOLDEN
+    from paccmann_chemistry_amd import utils as U
+    g = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    flat, offs = torch.from_numpy(g['flat']), g['offsets']
+    batch = [flat[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    packed = bool(int(g['packed']))
+    for _ in range(3):
+        got = U.prepare_batch_on_device(
+            batch, packed, input_keep=float(g['input_keep']), device=_dev(),
+            keep_mask=torch.from_numpy(g['keep']))
+        for out, key in zip(got, ('enc', 'dec', 'tgt')):
+            if packed:
+                assert torch.equal(out.batch_sizes,
+                                   torch.from_numpy(g['batch_sizes']))
+                out = out.data
+            assert torch.equal(out.cpu(), torch.from_numpy(g[key])), key
 
 
 def test_prepare_batch_on_device_bernoulli():

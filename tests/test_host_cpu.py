@@ -302,3 +302,61 @@ def test_packed_to_padded_sorted_batch():
     seq = [torch.tensor([5, 6, 7]), torch.tensor([8, 9]), torch.tensor([4])]
     out = packed_to_padded(seq, [])
     assert out.tolist() == [[5.0, 8.0, 4.0], [6.0, 9.0, 0.0], [7.0, 0.0, 0.0]]
+
+
+@pytest.mark.parametrize('name', ['prepare_padded', 'prepare_packed'])
+def test_batch_preparation_against_reference_fixture(name, monkeypatch):
+    """The host-side restatements of sequential_data_preparation /
+    packed_sequential_data_preparation against what the REFERENCE produced for
+    the same batch (tests/golden/prepare_*.npz, oracle/make_golden.py), with
+    the reference's recorded Bernoulli draws injected."""
+    from conftest import GOLDEN
+    from paccmann_chemistry_amd import utils as U
+    g = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    flat, offs = torch.from_numpy(g['flat']), g['offsets']
+    batch = [flat[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    keep = torch.from_numpy(g['keep']).float()
+    cursor = {'at': 0}
+
+    def draws(rows, input_keep):
+        at = cursor['at']
+        cursor['at'] += rows
+        return keep[at:at + rows]
+
+    monkeypatch.setattr(U, '_dropout_rows', draws)
+    cpu = torch.device('cpu')
+    if int(g['packed']):
+        enc, dec, tgt = U.packed_sequential_data_preparation(
+            batch, input_keep=float(g['input_keep']), device=cpu)
+        assert torch.equal(enc.batch_sizes, torch.from_numpy(g['batch_sizes']))
+        enc, dec, tgt = enc.data, dec.data, tgt.data
+    else:
+        enc, dec, tgt = U.sequential_data_preparation(
+            torch.nn.utils.rnn.pad_sequence(batch),
+            input_keep=float(g['input_keep']), device=cpu)
+    assert cursor['at'] == keep.numel()
+    assert torch.equal(enc, torch.from_numpy(g['enc']))
+    assert torch.equal(dec, torch.from_numpy(g['dec']))
+    assert torch.equal(tgt, torch.from_numpy(g['tgt']))
+    assert 0 < int((dec != enc).sum())     # the draws did drop tokens
+
+
+def test_packed_to_padded_follows_stop_tokens():
+    """utils/utils.py:171-203 derives the ended rows from STOP targets."""
+    from paccmann_chemistry_amd.utils import packed_to_padded
+    seqs = [torch.tensor([2, 5, 6, 3]), torch.tensor([2, 7, 8, 3]),
+            torch.tensor([2, 9, 3]), torch.tensor([2, 3])]
+    tgt = [torch.cat([q[1:], torch.zeros(1, dtype=torch.long)]) for q in seqs]
+    packed = torch.nn.utils.rnn.pack_sequence(tgt)
+    steps, prev = [], 0
+    for n in packed.batch_sizes.tolist():
+        steps.append(packed.data[prev:prev + n])
+        prev += n
+    outs = [torch.arange(10, 10 + n).float()
+            for n in packed.batch_sizes.tolist()]
+    want = torch.tensor([[10., 10, 10, 10], [11, 11, 11, 11],
+                         [12, 12, 12, 0], [13, 13, 0, 0]])
+    assert torch.equal(packed_to_padded(outs, steps), want)
+    assert torch.equal(packed_to_padded(outs), want)
+    with pytest.raises(ValueError):
+        packed_to_padded([outs[0], outs[0][:2]], steps)   # no STOP seen yet

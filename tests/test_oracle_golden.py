@@ -189,3 +189,23 @@ def test_aten_cell_switch_matches_restatement():
     finally:
         O.ATEN_CELL = False
     assert torch.allclose(plain, aten, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', golden_names('beam_'))
+def test_beam_generation(name):
+    """The oracle's beam branch (vae.py:439-488 + search.py:169-275) against
+    the reference's own beams: best sequence, every beam and its score."""
+    g = Golden(name)
+    p = g.params
+    dec = O.sub_params(g.weights, 'decoder')
+    with torch.no_grad():
+        best, beams = O.generate_from_latent_beam(
+            dec, g.tensor('z')[0], g.tensor('prime'),
+            int(g.data['generate_len']), p['stack_depth'],
+            int(g.data['beam_width']), int(g.data['top_tokens']),
+            float(g.data['temperature']), p.get('use_stack', True))
+    assert np.array_equal(best.numpy(), g.data['tokens'])
+    got_tokens = np.array([[beam[0] for beam in row] for row in beams])
+    got_scores = np.array([[beam[1] for beam in row] for row in beams])
+    assert np.array_equal(got_tokens, g.data['beam_tokens'])
+    assert np.allclose(got_scores, g.data['beam_scores'], rtol=1e-6, atol=0)

@@ -131,3 +131,69 @@ def test_resume_reproduces_uninterrupted_run(tmp_path):
     epoch(vae, opt, nxt)
     for key, val in vae.state_dict().items():
         assert torch.equal(val, straight[key]), key
+
+
+def test_flat_adam_resume_and_bad_token_in_loop(tmp_path):
+    """The bench's optimizer (dp.FlatAdam over flat gradient buckets) through
+    train_vae with save_checkpoint / load_checkpoint: a resumed run equals the
+    uninterrupted one bit for bit.  And the loop's single per-step
+    device->host read (TeacherVAE.loss_item) reports out-of-vocabulary ids."""
+    import paccmann_chemistry_amd as P
+    from paccmann_chemistry_amd import dp
+    from paccmann_chemistry_amd.training import (
+        load_checkpoint, save_checkpoint, train_vae
+    )
+    from paccmann_chemistry_amd.utils import collate_fn
+    params = {
+        'latent_dim': 16, 'rnn_cell_size': 64, 'embedding_size': 24,
+        'vocab_size': 24, 'stack_width': 8, 'stack_depth': 10, 'n_layers': 2,
+        'dropout': 0.0, 'batch_size': 32, 'batch_mode': 'padded',
+        'embedding': 'one_hot', 'use_stack': True, 'bidirectional': False
+    }
+    loader = torch.utils.data.DataLoader(
+        _dataset(128, 24, 5), batch_size=32, shuffle=False, drop_last=True,
+        collate_fn=collate_fn)
+    os.makedirs(tmp_path / 'weights')
+    logger = logging.getLogger('test_train_loop')
+    kw = dict(search=P.GreedySearch(), lr=5e-3, kl_growth=0.003, input_keep=1.,
+              log_interval=10 ** 9, eval_interval=10 ** 9,
+              save_interval=10 ** 9, logger=logger, batch_mode='padded')
+
+    def fresh():
+        torch.manual_seed(11)
+        vae = P.TeacherVAE(P.StackGRUEncoder(params),
+                           P.StackGRUDecoder(params)).to('cuda')
+        buckets = dp.GradientBuckets(vae, overlap=False)
+        return vae, dp.FlatAdam(buckets, lr=5e-3)
+
+    def epoch(vae, opt, e, data=loader):
+        torch.manual_seed(100 + e)
+        train_vae(e, vae, data, data, _Language(), str(tmp_path),
+                  persistent_optimizer=opt, **kw)
+
+    vae, opt = fresh()
+    start = {k: v.clone() for k, v in vae.state_dict().items()}
+    epoch(vae, opt, 0)
+    epoch(vae, opt, 1)
+    straight = {k: v.clone() for k, v in vae.state_dict().items()}
+    assert opt.step_count == 8
+    moved = [k for k in straight if not torch.equal(straight[k], start[k])]
+    assert len(moved) >= 30
+
+    vae, opt = fresh()
+    epoch(vae, opt, 0)
+    save_checkpoint(str(tmp_path / 'flat.pt'), vae, opt, 1, {'ep_loss': 0})
+    vae, opt = fresh()
+    nxt, _ = load_checkpoint(str(tmp_path / 'flat.pt'), vae, opt)
+    assert nxt == 1 and opt.step_count == 4
+    epoch(vae, opt, nxt)
+    for key, val in vae.state_dict().items():
+        assert torch.equal(val, straight[key]), key
+
+    bad = [seq.clone() for seq in _dataset(32, 24, 6)]
+    bad[5][2] = 999
+    bad_loader = torch.utils.data.DataLoader(
+        bad, batch_size=32, shuffle=False, collate_fn=collate_fn)
+    with pytest.raises(RuntimeError, match='index out of range'):
+        epoch(vae, opt, 2, bad_loader)
+    vae.check_tokens()   # the status word was cleared by the raise
