@@ -37,6 +37,9 @@ extern "C" {
 
 /* bits of the int32 status word a forward call leaves on the device */
 #define PCM_STATUS_BAD_TOKEN 1 /* a token id outside [0, vocab) was clamped */
+#define PCM_STATUS_TIMEOUT 2   /* a hand-off inside the persistent forward kernel
+                                  gave up (its blocks were not all resident):
+                                  the call's outputs are not valid */
 
 /* Model geometry of one StackGRU (stack_rnn.py:46-56). */
 typedef struct pcm_dims {

@@ -9,13 +9,17 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpaccmann_hip.so')
+# (PCM_LIBRARY: a diagnostics build of the same library, e.g. tools/bin/*.so)
+LIB_PATH = os.environ.get(
+    'PCM_LIBRARY', os.path.join(_HERE, 'libpaccmann_hip.so')
+)
 PCM_MAX_LAYERS = 8
 ABI_VERSION = 3
 
 SEARCH_GREEDY = 0
 SEARCH_SAMPLING = 1
 STATUS_BAD_TOKEN = 1
+STATUS_TIMEOUT = 2
 
 c_float_p = ctypes.c_void_p  # device pointers travel as plain addresses
 

@@ -119,6 +119,48 @@ static SideStream *side_stream() {
     return &s;
 }
 
+// ---- second stream for the second half of the batch ("two chains") --------------
+// The recurrence is a chain of short dependent launches whose fixed costs
+// (launch gap, prologue, epilogue) leave the CUs idle between MFMA phases.  Rows
+// are independent, so the batch is walked as two half-batch chains on two
+// streams: their launches interleave on the chip and one chain's MFMA phase
+// fills the other's gaps.  Same kernels, same arithmetic per row.
+static SideStream g_chain[16];
+
+static SideStream *chain_stream() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    SideStream &s = g_chain[dev];
+    if (!s.ok) {
+        if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) !=
+            hipSuccess)
+            return nullptr;
+        for (int i = 0; i < 8; ++i)
+            if (hipEventCreateWithFlags(&s.ev[i], hipEventDisableTiming) !=
+                hipSuccess)
+                return nullptr;
+        s.ok = true;
+    }
+    return &s;
+}
+
+// Row at which the second chain starts (0 = one chain, the default).
+// PCM_CHAINS=2 walks the batch as two half-batch chains.
+static int chain_split(const SGLayout &lay) {
+    static const int force = [] {
+        const char *e = getenv("PCM_CHAINS");
+        return e ? atoi(e) : 0;
+    }();
+    static const bool overlap = getenv("PCM_OVERLAP") != nullptr;
+    if (force == 1 || overlap || (lay.H % 64) != 0) return 0;
+    // measured on MI355X at batch 512: two half-batch chains take 27.6 ms per
+    // training step against 26.9 ms for one chain (co-running kernels stretch
+    // each other by more than the hidden gaps), so one chain is the default
+    if (force != 2) return 0;
+    if (lay.B < 64) return 0;
+    return (int)pcm_round_up(lay.B / 2, 32);
+}
+
 // make `waiter` wait for everything enqueued on `signal` so far
 static void stream_wait(SideStream *s, hipStream_t signal, hipStream_t waiter) {
     hipEvent_t e = s->ev[s->next];
@@ -182,8 +224,10 @@ int pcm_sg_layout(const pcm_dims *d, int steps, int training, int dropout,
         const size_t per = o->training ? steps : 1;
         o->off_S = take(off, slots * o->B * o->DW);
         o->off_av = take(off, per * o->B * o->AVW);
-        o->off_xtop = take(off, per * o->B * o->Wp);
+        o->off_xtop = take(off, (size_t)steps * o->B * o->Wp);
     }
+    o->off_sync = take(off, pcm_persist_fwd_sync_words());
+    o->off_cpre = take(off, o->use_stack ? (size_t)steps * o->B * 64 : 0);
     o->off_tokg = take(off, (size_t)o->V * 3 * o->Hn);
     for (int l = 0; l < o->L; ++l) {
         o->off_wpack[l] = take(off, (size_t)3 * o->Hn * o->Kp[l]);
@@ -194,6 +238,7 @@ int pcm_sg_layout(const pcm_dims *d, int steps, int training, int dropout,
 }
 
 static const size_t GEMM_SCRATCH_FLOATS = 40u * 1024u * 1024u;
+
 
 int pcm_sg_scratch(const SGLayout &lay, SGScratch *o) {
     memset(o, 0, sizeof(*o));
@@ -237,18 +282,24 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
                         float *const *bpack, const StepBufs &sb,
                         const int32_t *lengths, int t, float drop_p,
                         uint64_t seed, int32_t *status, hipStream_t st,
-                        int rows = -1) {
-    // rows: the length-sorted prefix of the batch still running at this step
-    // (packed mode with a shrinking active batch); -1 = all of it
-    const int Bt = rows < 0 ? lay.B : rows;
-    if (Bt == 0) return PCM_OK;
+                        int rows = -1, int b0 = 0) {
+    // The step over batch rows [b0, b0 + rows): rows = the length-sorted prefix
+    // of the batch still running at this step (packed mode with a shrinking
+    // active batch), or one chain's half of it; -1 = everything from b0 on.
+    // StepBufs holds whole-batch base pointers, the slice is applied here.
+    const int Bt = rows < 0 ? lay.B - b0 : rows;
+    if (Bt <= 0) return PCM_OK;
+    const size_t oH = (size_t)b0 * lay.Hp, oG = (size_t)b0 * 4 * lay.H;
+    const size_t oS = (size_t)b0 * lay.DW, oAV = (size_t)b0 * lay.AVW;
+    const size_t oX = (size_t)b0 * lay.Wp;
+    const int32_t *len = lengths ? lengths + b0 : nullptr;
     if (lay.use_stack) {
         StackFwdArgs s;
-        s.htop = sb.h_prev[lay.L - 1];
-        s.S_prev = sb.S_prev; s.S_new = sb.S_new;
+        s.htop = sb.h_prev[lay.L - 1] + oH;
+        s.S_prev = sb.S_prev + oS; s.S_new = sb.S_new + oS;
         s.ctrl_w = w->ctrl_w; s.ctrl_b = w->ctrl_b;
         s.push_w = w->push_w; s.push_b = w->push_b;
-        s.av = sb.av; s.xtop = sb.xtop; s.lengths = lengths;
+        s.av = sb.av + oAV; s.xtop = sb.xtop + oX; s.lengths = len;
         s.B = Bt; s.H = lay.H; s.Hp = lay.Hp; s.D = lay.D; s.W = lay.W;
         s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
         pcm_probe_begin(PCM_K_STACK_FWD);
@@ -258,20 +309,21 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
     }
     for (int l = 0; l < lay.L; ++l) {
         CellFwdArgs c;
-        c.xin = l == 0 ? sb.xtop : (lay.dropout ? sb.xdrop[l] : sb.h_new[l - 1]);
-        c.hprev = sb.h_prev[l];
+        c.xin = l == 0 ? sb.xtop + oX
+                       : (lay.dropout ? sb.xdrop[l] : sb.h_new[l - 1]) + oH;
+        c.hprev = sb.h_prev[l] + oH;
         c.wpack = wpack[l]; c.bpack = bpack[l];
         c.tokg = l == 0 ? sv_tokg : nullptr;
-        c.tok = l == 0 ? sb.tok : nullptr;
-        c.hnew = sb.h_new[l];
-        c.gates = sb.gates[l];
-        c.xdrop = (lay.dropout && l + 1 < lay.L) ? sb.xdrop[l + 1] : nullptr;
-        c.lengths = lengths; c.status = status;
+        c.tok = l == 0 ? sb.tok + b0 : nullptr;
+        c.hnew = sb.h_new[l] + oH;
+        c.gates = sb.gates[l] ? sb.gates[l] + oG : nullptr;
+        c.xdrop = (lay.dropout && l + 1 < lay.L) ? sb.xdrop[l + 1] + oH : nullptr;
+        c.lengths = len; c.status = status;
         c.ldx = l == 0 ? lay.Wp : lay.Hp;
         c.nx_chunks = lay.Kxp[l] / 64; c.nh_chunks = lay.Hp / 64;
         c.Kp = lay.Kp[l];
         c.B = Bt; c.H = lay.H; c.Hn = lay.Hn; c.Hp = lay.Hp; c.V = lay.V;
-        c.t = t; c.next_layer = l + 1;
+        c.t = t; c.next_layer = l + 1; c.b_off = b0;
         c.drop_p = drop_p; c.inv_keep = drop_p < 1.f ? 1.f / (1.f - drop_p) : 0.f;
         c.seed = seed;
         pcm_probe_begin(PCM_K_CELL_FWD, l);
@@ -280,6 +332,14 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         if (rc) return rc;
     }
     return PCM_OK;
+}
+
+// rows [b0, b0 + n) that chain c walks at a step with `total` active rows
+// (the batch's length-sorted prefix); split == 0: one chain takes them all
+static inline void chain_rows(int c, int split, int total, int *b0, int *n) {
+    if (split == 0) { *b0 = 0; *n = total; return; }
+    if (c == 0) { *b0 = 0; *n = total < split ? total : split; }
+    else { *b0 = split; *n = total > split ? total - split : 0; }
 }
 
 // pack weights + token gate table into the workspace
@@ -497,7 +557,20 @@ int pcm_stackgru_forward(const pcm_dims *dims,
         wpack[l] = sv + lay.off_wpack[l];
         bpack[l] = sv + lay.off_bpack[l];
     }
-    for (int t = 0; t < steps; ++t) {
+    // the tuned shape walks all steps in ONE persistent launch
+    const bool persist = !active_rows && pcm_persist_fwd_supported(lay, lengths);
+    if (persist) {
+        rc = pcm_launch_persist_fwd(lay, sv, weights, tokens, dropout_p, seed,
+                                    status, (unsigned *)(sv + lay.off_sync), st);
+        if (rc) return rc;
+    }
+    // one chain over the whole batch, or two half-batch chains on two streams
+    int split = persist ? 0 : chain_split(lay);
+    SideStream *cs = split ? chain_stream() : nullptr;
+    if (!cs) split = 0;
+    const int nch = split ? 2 : 1;
+    if (split) stream_wait(cs, st, cs->stream);   // fork: state is initialised
+    for (int t = 0; t < steps && !persist; ++t) {
         StepBufs sb;
         memset(&sb, 0, sizeof(sb));
         for (int l = 0; l < lay.L; ++l) {
@@ -517,11 +590,17 @@ int pcm_stackgru_forward(const pcm_dims *dims,
             sb.xtop = sv + lay.xtop_index(t);
         }
         sb.tok = tokens + (size_t)t * lay.B;
-        rc = enqueue_step(lay, weights, sv + lay.off_tokg, wpack, bpack, sb,
-                          lengths, t, dropout_p, seed, status, st,
-                          active_rows ? active_rows[t] : -1);
-        if (rc) return rc;
+        const int total = active_rows ? active_rows[t] : lay.B;
+        for (int c = 0; c < nch; ++c) {
+            int b0, n;
+            chain_rows(c, split, total, &b0, &n);
+            rc = enqueue_step(lay, weights, sv + lay.off_tokg, wpack, bpack, sb,
+                              lengths, t, dropout_p, seed, status,
+                              c == 0 ? st : cs->stream, n, b0);
+            if (rc) return rc;
+        }
     }
+    if (split) stream_wait(cs, cs->stream, st);   // join
     if (active_rows) {
         // each row's state after ITS last step (slot lengths[b])
         if (h_final)
@@ -885,13 +964,30 @@ int pcm_stackgru_backward(const pcm_dims *dims,
         return r;
     };
 
+    // one chain over the whole batch, or two half-batch chains on two streams
+    // (see chain_stream); everything below the loop runs on `st` after the join
+    int split = fused_bwd ? chain_split(lay) : 0;
+    SideStream *cs = split ? chain_stream() : nullptr;
+    if (!cs) split = 0;
+    const int nch = split ? 2 : 1;
+    if (split) stream_wait(cs, st, cs->stream);   // fork
+    auto total_rows = [&](int t) { return active_rows ? active_rows[t] : B; };
+    int cur_c[2] = {cur, cur};
     for (int t = T - 1; t >= 0; --t) {
-        // rows still running at step t (length-sorted prefix)
-        const int Bt = active_rows ? active_rows[t] : B;
+      for (int c = 0; c < nch; ++c) {
+        hipStream_t cst = c == 0 ? st : cs->stream;
+        // rows [b0, b0 + Bt) still running at step t in this chain
+        int b0, Bt, b0n, Btn = 0, b0p, Btp = 0;
+        chain_rows(c, split, total_rows(t), &b0, &Bt);
+        if (t + 1 < T) chain_rows(c, split, total_rows(t + 1), &b0n, &Btn);
+        if (t > 0) chain_rows(c, split, total_rows(t - 1), &b0p, &Btp);
+        const size_t oH = (size_t)b0 * Hp, oG = (size_t)b0 * 4 * H;
+        const int32_t *len = lengths ? lengths + b0 : nullptr;
+        int &cur = cur_c[c];
         int dtop_parts = 1;
         for (int l = L - 1; l >= 0 && Bt > 0; --l) {
-            float *gates = sv + lay.off_gates[l] + (size_t)t * B * 4 * H;
-            float *dhl = dh + (size_t)l * B * Hp;
+            float *gates = sv + lay.off_gates[l] + (size_t)t * B * 4 * H + oG;
+            float *dhl = dh + (size_t)l * B * Hp + oH;
             // gate derivatives: the top layer (it also receives d_out and
             // the stack-control path of step t+1) and every layer on the
             // generic path take them in their own launch; on the fused path
@@ -900,21 +996,20 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             // step t+1, which produces their last operand; only the first
             // step walked has no such launch above it)
             const bool by_stack =
-                l == L - 1 && lay.use_stack && t + 1 < T &&
-                (active_rows ? active_rows[t + 1] : B) > 0;
+                l == L - 1 && lay.use_stack && t + 1 < T && Btn > 0;
             if ((l == L - 1 || !fused_bwd) && !by_stack) {
                 GateBwdArgs g;
                 memset(&g, 0, sizeof(g));
                 g.dh = dhl;
                 g.dout = (l == L - 1 && d_out)
-                             ? d_out + (size_t)t * B * d_out_row_stride
+                             ? d_out + ((size_t)t * B + b0) * d_out_row_stride
                              : nullptr;
                 g.ld_dout = d_out_row_stride;
                 g.gates = gates;
-                g.hprev = sv + lay.off_hs[l] + (size_t)t * lay.hs_step();
-                g.lengths = lengths; g.B = Bt; g.H = H; g.Hp = Hp; g.t = t;
+                g.hprev = sv + lay.off_hs[l] + (size_t)t * lay.hs_step() + oH;
+                g.lengths = len; g.B = Bt; g.H = H; g.Hp = Hp; g.t = t;
                 pcm_probe_begin(PCM_K_GATE_BWD);
-                pcm_launch_gate_bwd(g, st);
+                pcm_launch_gate_bwd(g, cst);
                 pcm_probe_end(PCM_K_GATE_BWD);
             }
 
@@ -923,32 +1018,33 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                 cb.dgates = gates;
                 cb.wpackT = scf + sc.off_wpackT[l];
                 cb.dh = dhl;
-                cb.dx = l > 0 ? dh + (size_t)(l - 1) * B * Hp : dtop;
+                cb.dx = l > 0 ? dh + (size_t)(l - 1) * B * Hp + oH
+                              : dtop + (size_t)b0 * lay.Wp;
                 cb.ldx = l > 0 ? Hp : lay.Wp;
                 cb.dx_accumulate = l > 0 ? 1 : 0;
                 cb.dx_cols = l > 0 ? H : lay.Wp;
                 cb.B = Bt; cb.H = H; cb.Hp = Hp;
                 cb.NT = H + lay.Kxp[l];
-                cb.t = t; cb.layer = l;
+                cb.t = t; cb.layer = l; cb.b_off = b0;
                 cb.drop_p = (l > 0 && drop) ? dropout_p : 0.f;
                 cb.inv_keep = cb.drop_p > 0.f ? 1.f / (1.f - dropout_p) : 1.f;
                 cb.seed = seed;
                 cb.gates_low = nullptr; cb.hprev_low = nullptr;
-                cb.lengths = lengths;
+                cb.lengths = len;
                 cb.xparts = 1; cb.xpart_stride = (long long)B * lay.Wp;
                 if (l > 0) {
                     cb.gates_low = sv + lay.off_gates[l - 1] +
-                                   (size_t)t * B * 4 * H;
+                                   (size_t)t * B * 4 * H + oG;
                     cb.hprev_low = sv + lay.off_hs[l - 1] +
-                                   (size_t)t * lay.hs_step();
+                                   (size_t)t * lay.hs_step() + oH;
                 }
                 if (l == 0) dtop_parts = pcm_cell_bwd_xparts(cb);
                 pcm_probe_begin(PCM_K_CELL_BWD, l);
-                pcm_launch_cell_bwd(cb, st);
+                pcm_launch_cell_bwd(cb, cst);
                 pcm_probe_end(PCM_K_CELL_BWD, l);
                 continue;
             }
-            // generic path (H not a multiple of 64):
+            // generic path (H not a multiple of 64; always one chain):
             // dh[l] += dGh . W_hh  (dGh = cols [0,2H) and [3H,4H) of gates)
             GemmBatch gb;
             gb.count = 0;
@@ -977,7 +1073,7 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                                             dtop, lay.Wp, Bt, lay.W, 3 * H);
                 gb.p[gb.count++] = p2;
             }
-            rc = pcm_gemm_launch(gb, gs, gsb, st);
+            rc = pcm_gemm_launch(gb, gs, gsb, cst);
             if (rc) return rc;
             if (!seg_ok) {
                 GemmBatch g2;
@@ -987,46 +1083,48 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                                             H, 1, dhl, Hp, Bt, H, H);
                 p3.accumulate = 1;
                 g2.p[0] = p3;
-                rc = pcm_gemm_launch(g2, gs, gsb, st);
+                rc = pcm_gemm_launch(g2, gs, gsb, cst);
                 if (rc) return rc;
             }
             if (use_tmp)
                 pcm_launch_dropout_add(dh + (size_t)(l - 1) * B * Hp, Hp, tmp, Hp,
-                                       Bt, H, seed, l, t, dropout_p, st);
+                                       Bt, H, seed, l, t, dropout_p, cst);
         }
         if (lay.use_stack && Bt > 0) {
+            const size_t oS = (size_t)b0 * lay.DW;
             StackBwdArgs s;
-            s.dS_next = dS[cur]; s.dS_prev = dS[cur ^ 1];
-            s.dtop = dtop;
+            s.dS_next = dS[cur] + oS; s.dS_prev = dS[cur ^ 1] + oS;
+            s.dtop = dtop + (size_t)b0 * lay.Wp;
             s.dtop_parts = dtop_parts;
             s.dtop_stride = (long long)B * lay.Wp;
-            s.S_prev = sv + lay.s_index(t);
-            s.av = sv + lay.av_index(t);
-            s.lengths = lengths;
+            s.S_prev = sv + lay.s_index(t) + oS;
+            s.av = sv + lay.av_index(t) + (size_t)b0 * lay.AVW;
+            s.lengths = len;
             s.B = Bt; s.H = H; s.Hp = Hp; s.D = lay.D; s.W = lay.W;
             s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
             // ... followed by the top layer's gate gradient of step t-1 (or,
             // at t == 0, the control path into the initial hidden state)
             s.gate_mode = t > 0 ? 1 : 2;
-            s.gate_B = t > 0 ? (active_rows ? active_rows[t - 1] : B) : Bt;
-            s.g_dh = dh + (size_t)(L - 1) * B * Hp;
+            s.gate_B = t > 0 ? Btp : Bt;
+            s.g_dh = dh + (size_t)(L - 1) * B * Hp + oH;
             s.g_dout = (t > 0 && d_out)
-                           ? d_out + (size_t)(t - 1) * B * d_out_row_stride
+                           ? d_out + ((size_t)(t - 1) * B + b0) * d_out_row_stride
                            : nullptr;
             s.g_ld_dout = d_out_row_stride;
             s.g_gates = t > 0 ? sv + lay.off_gates[L - 1] +
-                                    (size_t)(t - 1) * B * 4 * H
+                                    (size_t)(t - 1) * B * 4 * H + oG
                               : nullptr;
             s.g_hprev = t > 0 ? sv + lay.off_hs[L - 1] +
-                                    (size_t)(t - 1) * lay.hs_step()
+                                    (size_t)(t - 1) * lay.hs_step() + oH
                               : nullptr;
             s.ctrl_w = weights->ctrl_w; s.push_w = weights->push_w;
             pcm_probe_begin(PCM_K_STACK_BWD);
-            rc = pcm_launch_stack_bwd(s, st);
+            rc = pcm_launch_stack_bwd(s, cst);
             pcm_probe_end(PCM_K_STACK_BWD);
             if (rc) return rc;
             cur ^= 1;
         }
+      }
         // the control gradients of step t feed the gate kernel of step t-1
         // only as a READ, so rows >= t are final here
         if (t > 0 && next_bound < nbounds && T - t == bounds[next_bound]) {
@@ -1035,12 +1133,19 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             if (rc) return rc;
         }
     }
+    if (split) stream_wait(cs, cs->stream, st);   // join
     if (d_h0)
         for (int l = 0; l < L; ++l)
             pcm_launch_copy_rows(dh + (size_t)l * B * Hp, Hp,
                                  d_h0 + (size_t)l * B * H, H, B, H, st);
     if (d_stack0 && lay.use_stack)
-        pcm_launch_copy_rows(dS[cur], lay.DW, d_stack0, lay.DW, B, lay.DW, st);
+        for (int c = 0; c < nch; ++c) {
+            // (each chain's ping-pong slot flips on the steps IT walked)
+            const int b0 = c == 0 ? 0 : split, n = split ? (c == 0 ? split : B - split) : B;
+            pcm_launch_copy_rows(dS[cur_c[c]] + (size_t)b0 * lay.DW, lay.DW,
+                                 d_stack0 + (size_t)b0 * lay.DW, lay.DW, n,
+                                 lay.DW, st);
+        }
 
     // the remaining chunk(s) and the join with the side stream
     rc = flush_param_grads(0);

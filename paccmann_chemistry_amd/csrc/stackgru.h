@@ -19,7 +19,11 @@ struct SGLayout {
     size_t off_gates[PCM_MAX_LAYERS];  // T x B x 4H : r, z, n, W_hn.h+b_hn
     size_t off_S;      // training: (T+1) x B x D*W ; else 2 x B x D*W
     size_t off_av;     // training: T x B x AVW ; else B x AVW  (a[3], v[W])
-    size_t off_xtop;   // training: T x B x Wp ; else B x Wp
+    size_t off_xtop;   // T x B x Wp (a slot per step in both modes: the
+                       // persistent kernel hands it over at fresh addresses)
+    size_t off_sync;   // hand-off counters of the persistent kernel (words)
+    size_t off_cpre;   // T x B x 64: stack control / push pre-activations the
+                       // persistent kernel hands over (0 floats without a stack)
     size_t off_tokg;   // V x 3*Hn   token gate table (b_ih0 folded in)
     size_t off_wpack[PCM_MAX_LAYERS];  // 3*Hn x Kp[l]
     size_t off_bpack[PCM_MAX_LAYERS];  // 4*Hn
@@ -32,9 +36,7 @@ struct SGLayout {
     size_t av_index(int t) const {
         return off_av + (size_t)(training ? t : 0) * B * AVW;
     }
-    size_t xtop_index(int t) const {
-        return off_xtop + (size_t)(training ? t : 0) * B * Wp;
-    }
+    size_t xtop_index(int t) const { return off_xtop + (size_t)t * B * Wp; }
 };
 
 int pcm_sg_layout(const pcm_dims *dims, int steps, int training, int dropout,
@@ -73,6 +75,8 @@ struct CellFwdArgs {
     int32_t *status;
     int ldx, nx_chunks, nh_chunks, Kp;
     int B, H, Hn, Hp, V, t, next_layer;
+    int b_off;          // batch index of row 0 (a launch over a slice of the
+                        // batch: the dropout hash is a function of the GLOBAL row)
     float drop_p, inv_keep;
     uint64_t seed;
 };
@@ -102,6 +106,16 @@ struct PackArgs {
     int H, Hn, Hp, Kx, Kxp, Kp, ld_ih, x_off, fold_bih;
 };
 int pcm_launch_pack(const PackArgs &a, hipStream_t stream);
+
+// Persistent forward recurrence (persist_fwd.hip): one launch for all T steps
+// when the shape is the tuned one (H = 512, L = 2, stack width <= 64, padded
+// batch of 257..512 rows); the launch chain otherwise.
+bool pcm_persist_fwd_supported(const SGLayout &lay, const int32_t *lengths);
+size_t pcm_persist_fwd_sync_words();
+int pcm_launch_persist_fwd(const SGLayout &lay, float *sv,
+                           const pcm_stackgru_params *w, const int64_t *tokens,
+                           float dropout_p, uint64_t seed, int32_t *status,
+                           unsigned *sync, hipStream_t stream);
 
 // hs[l][0] <- h0 (or 0), with zero padding; S[0] <- stack0 (or 0)
 int pcm_launch_init_state(const SGLayout &lay, float *saved, const float *h0,
@@ -149,6 +163,7 @@ struct CellBwdArgs {
     int xparts;              // K-part partials of dx (set by the launcher)
     long long xpart_stride;  // floats between partials of dx (>= B_total * ldx)
     int t, layer;
+    int b_off;               // batch index of row 0 (dropout hash, see CellFwdArgs)
     float drop_p, inv_keep;  // drop_p > 0: mask dx with the forward's dropout
     uint64_t seed;
     // fused gate gradient of the layer below (l > 0): once dx completes

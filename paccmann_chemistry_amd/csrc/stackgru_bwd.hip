@@ -612,7 +612,7 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
             const int j = n - H;
             if (j >= a.dx_cols) continue;
             if (a.drop_p > 0.f)
-                v *= pcm_dropout_scale(a.seed, a.layer, a.t, b, j, a.drop_p,
+                v *= pcm_dropout_scale(a.seed, a.layer, a.t, b + a.b_off, j, a.drop_p,
                                        a.inv_keep);
             float *dst = a.dx + (long long)b * a.ldx + j;
             if (a.gates_low) {

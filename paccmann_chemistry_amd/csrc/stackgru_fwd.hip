@@ -112,7 +112,7 @@ __device__ __forceinline__ void cell_fwd_element(const CellFwdArgs &a, int b,
     }
     if (a.xdrop)
         a.xdrop[(long long)b * a.Hp + j] =
-            hn * pcm_dropout_scale(a.seed, a.next_layer, a.t, b, j, a.drop_p,
+            hn * pcm_dropout_scale(a.seed, a.next_layer, a.t, b + a.b_off, j, a.drop_p,
                                    a.inv_keep);
 }
 

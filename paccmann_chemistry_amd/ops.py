@@ -33,8 +33,18 @@ def check_status(status, what='token ids'):
     """Raise the RuntimeError the reference's embedding lookup would raise for
     ids outside the vocabulary (generate_latent_codes.py:126 relies on it).
     One device->host read, so callers do it once per forward."""
-    if status is not None and int(status.item()) & _lib.STATUS_BAD_TOKEN:
+    if status is None:
+        return
+    word = int(status.item())
+    if word:
         status.zero_()
+    if word & _lib.STATUS_TIMEOUT:
+        raise _lib.PaccmannHipError(
+            'the persistent forward kernel gave up waiting for its peer '
+            'blocks (GPU shared with other work?); results are invalid -- '
+            'set PCM_PERSIST=0 to use the launch chain'
+        )
+    if word & _lib.STATUS_BAD_TOKEN:
         raise RuntimeError(f'index out of range in self ({what})')
 
 

@@ -330,9 +330,15 @@ class TeacherVAE(nn.Module):
         value, status = torch.cat(
             [loss.detach().reshape(1).double(), flags.double()]
         ).tolist()
-        if int(status) & _lib.STATUS_BAD_TOKEN:
+        if int(status):
             for word in words:
                 word.zero_()
+        if int(status) & _lib.STATUS_TIMEOUT:
+            raise _lib.PaccmannHipError(
+                'the persistent forward kernel gave up waiting for its peer '
+                'blocks; results are invalid (PCM_PERSIST=0 disables it)'
+            )
+        if int(status) & _lib.STATUS_BAD_TOKEN:
             raise RuntimeError('index out of range in self (token ids)')
         return value
 

@@ -249,3 +249,31 @@ def test_large_stack_gradients_and_limit():
         mu, _ = enc.encoder_train_step(tokens.to(_dev()))
         r_mu, _ = O.encoder_forward(enc_sd, tokens, 130)
     assert _rel_to_max(mu, r_mu) < 1e-5
+
+
+@pytest.mark.parametrize('env', [
+    {'PCM_PERSIST': '1'},
+    {'PCM_CHAINS': '2'},
+])
+def test_opt_in_recurrence_variants(env):
+    """The two forms of the recurrence that are built but not the default (both
+    measured slower than the launch chain at batch 512): the
+    persistent weight-stationary forward kernel with in-launch group hand-offs
+    (PCM_PERSIST=1) and the batch walked as two half-batch chains on two
+    streams (PCM_CHAINS=2).  The switches are read once per process, hence a
+    child process: the full-size training step (every gradient against the
+    oracle, with and without dropout), the B=4096 rows and the packed / padded
+    data-parallel shard test."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, '-m', 'pytest', '-x', '-q', '-p', 'no:cacheprovider',
+           os.path.join(ROOT, 'tests', 'test_gpu_fullsize.py'),
+           os.path.join(ROOT, 'tests', 'test_gpu_parity.py'), '-k',
+           'full_size_training or batch_4096 or shards_sum or determinism or '
+           'vae_config_golden']
+    res = subprocess.run(cmd, env=dict(os.environ, **env), cwd=ROOT,
+                         capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
+    assert ' passed' in res.stdout
