@@ -253,6 +253,16 @@ def main():
     # per-kernel launch durations: one extra untimed step per kernel family
     # (every rank runs the step, rank 0 records)
     probed = []
+    probe_offset_us = 0.0
+    if args.probe and not args.ragged and rank == 0:
+        # what the event pair adds to a reading (see pcm_probe_calibrate)
+        p_us, c_us = ctypes.c_double(), ctypes.c_double()
+        _lib.check(lib.pcm_probe_calibrate(
+            400, ctypes.byref(p_us), ctypes.byref(c_us),
+            _lib.stream_ptr(dev)), 'probe calibrate')
+        probe_offset_us = max(p_us.value - c_us.value, 0.0)
+        calibration = {'empty_launch_probe_us': p_us.value,
+                       'empty_launch_chain_us': c_us.value}
     if args.probe and not args.ragged:
         probe_ms, probe_n, dropped = (ctypes.c_double(), ctypes.c_int64(),
                                       ctypes.c_int64())
@@ -285,6 +295,7 @@ def main():
         for name, bound, work, total_ms, launches in probed:
             if launches <= 0:
                 continue
+            total_ms = max(total_ms - launches * probe_offset_us * 1e-3, 1e-9)
             avg_s = total_ms / launches * 1e-3
             if name.startswith('gemm_tn'):
                 # the family's launches differ in size: price them together
@@ -308,7 +319,10 @@ def main():
             roofline['sample'] = (
                 'kernel begin -> end from the events hipExtLaunchKernelGGL '
                 'binds to each dispatch, every launch of one untimed step '
-                'after the timed region')
+                'after the timed region, minus what the event pair adds to '
+                'an empty dependent launch (probe_calibration)')
+            roofline['probe_calibration'] = dict(
+                calibration, offset_us=probe_offset_us)
         step_tflops = value * 29.8e6 / 1e12
         step_roofline = {
             'bound': 'mfma', 'achieved': step_tflops,

@@ -63,8 +63,10 @@ def main():
 
     lengths = sorted(W.ragged_lengths(batch, seq_len, 4321), reverse=True)
     ragged = W.synthetic_tokens(seq_len, batch, p['vocab_size'], 1235, lengths)
+    # (packed on the host, ONE copy to the device: 4096 per-row copies would
+    # show up in a profile as if the library issued them)
     packed = torch.nn.utils.rnn.pack_sequence(
-        [ragged[:n, b].to(dev) for b, n in enumerate(lengths)])
+        [ragged[:n, b] for b, n in enumerate(lengths)]).to(dev)
     torch.manual_seed(1234)
     q = dict(p, batch_mode='packed')
     vae_packed = P.TeacherVAE(P.StackGRUEncoder(q), P.StackGRUDecoder(q)).to(dev)

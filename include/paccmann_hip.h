@@ -94,6 +94,17 @@ int pcm_device_check(void);
  * launches are recorded.  Not thread safe; one device per process.
  */
 int pcm_probe_enable(int32_t kernel_id, int32_t max_launches);
+/*
+ * What the event pair itself adds to a reading: `launches` empty dependent
+ * kernels timed twice on `stream` -- by two events around the whole run
+ * (chain_us: the chain's wall clock per launch, the cost a launch has inside the
+ * recurrence) and by a pair bound to each launch (probe_us).  Subtracting
+ * probe_us - chain_us from a probed average gives the launch's share of the
+ * chain's wall clock, which is what a rocprofv3 kernel trace shows for
+ * back-to-back dependent launches.  Synchronises the stream.
+ */
+int pcm_probe_calibrate(int32_t launches, double *probe_us, double *chain_us,
+                        void *stream);
 int pcm_probe_read(double *total_ms, int64_t *launches, int64_t *dropped);
 
 /* StackGRU over a whole sequence ------------------------------------------*/

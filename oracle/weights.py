@@ -40,7 +40,7 @@ LOSS_CURVES = {
             'batch_mode': 'padded', 'embedding': 'one_hot',
             'use_stack': True, 'bidirectional': False
         },
-        'seq_len': 120, 'steps': 60, 'steps_per_epoch': 30, 'lr': 5e-4,
+        'seq_len': 120, 'steps': 240, 'steps_per_epoch': 30, 'lr': 5e-4,
         'kl_growth': 0.0015, 'seed': 7100,
     },
 }

@@ -56,6 +56,12 @@ PROTOTYPES = {
     'pcm_last_error': (ctypes.c_char_p, []),
     'pcm_device_check': (ctypes.c_int, []),
     'pcm_probe_enable': (ctypes.c_int, [_I32, _I32]),
+    'pcm_probe_calibrate': (
+        ctypes.c_int, [
+            _I32, ctypes.POINTER(ctypes.c_double),
+            ctypes.POINTER(ctypes.c_double), _VP
+        ]
+    ),
     'pcm_probe_read': (
         ctypes.c_int, [
             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_I64),

@@ -425,6 +425,57 @@ int pcm_probe_enable(int32_t kernel_id, int32_t max_launches) {
     return PCM_OK;
 }
 
+// a kernel that does nothing, for pcm_probe_calibrate
+__global__ void pcm_empty_kernel(int *sink) {
+    if (sink && threadIdx.x == 0 && blockIdx.x == 0x7fffffff) *sink = 0;
+}
+
+int pcm_probe_calibrate(int32_t launches, double *probe_us, double *chain_us,
+                        void *stream) {
+    PCM_REQUIRE(launches >= 8 && launches <= 4096 && probe_us && chain_us,
+                PCM_EINVAL, "probe_calibrate: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int keep_id = g_pcm_probe_id;
+    g_pcm_probe_id = 0;
+    std::vector<hipEvent_t> ev(2 * (size_t)launches + 2);
+    for (auto &e : ev) {
+        hipError_t err = hipEventCreate(&e);
+        PCM_REQUIRE(err == hipSuccess, PCM_EDEVICE, "probe_calibrate: %s",
+                    hipGetErrorString(err));
+    }
+    auto run = [&](bool bound) {
+        for (int i = 0; i < launches; ++i) {
+            if (bound)
+                hipExtLaunchKernelGGL(pcm_empty_kernel, dim3(256), dim3(256), 0,
+                                      st, ev[2 * i], ev[2 * i + 1], 0,
+                                      (int *)nullptr);
+            else
+                hipLaunchKernelGGL(pcm_empty_kernel, dim3(256), dim3(256), 0, st,
+                                   (int *)nullptr);
+        }
+    };
+    run(false);                                   // warm the code object
+    // (1) the chain's wall clock per dependent launch, no per-launch events
+    (void)hipEventRecord(ev[2 * launches], st);
+    run(false);
+    (void)hipEventRecord(ev[2 * launches + 1], st);
+    // (2) the same launches with a (start, stop) pair bound to each
+    run(true);
+    (void)hipStreamSynchronize(st);
+    float wall_ms = 0.f, sum_ms = 0.f;
+    (void)hipEventElapsedTime(&wall_ms, ev[2 * launches], ev[2 * launches + 1]);
+    for (int i = 0; i < launches; ++i) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+        sum_ms += ms;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    g_pcm_probe_id = keep_id;
+    *chain_us = (double)wall_ms * 1e3 / launches;
+    *probe_us = (double)sum_ms * 1e3 / launches;
+    return pcm_check_launch("probe_calibrate");
+}
+
 int pcm_probe_read(double *total_ms, int64_t *launches, int64_t *dropped) {
     probe_drain();
     if (total_ms) *total_ms = g_probe_ms;

@@ -577,8 +577,8 @@ int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
         for (int i = 0; i < batch.count; ++i)
             wide = wide && batch.p[i].M > 64 && batch.p[i].N > 64;
         const dim3 tn_grid((unsigned)(tn_tiles * pl.splits));
-        // the weight-gradient probe (id 6) times the wide launches only
-        hipEvent_t probe_keep = g_pcm_probe_start;
+        // the weight-gradient probe (id 6) times the wide launches only (a
+        // cleared start event makes pcm_probe_end_ drop the pair)
         if (!wide && g_pcm_probe_id == PCM_K_DW_GEMM) g_pcm_probe_start = nullptr;
         if (wide)
             PCM_LAUNCH(gemm_tn_kernel<0>, tn_grid, dim3(256),
@@ -588,7 +588,6 @@ int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
             PCM_LAUNCH(gemm_tn_kernel<-1>, tn_grid, dim3(256),
                                g_pcm_gemm_lds_pad, stream, batch, pl.splits,
                                slab, slabs, tmap);
-        g_pcm_probe_start = probe_keep;
     } else if (pl.big)
         hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), g_pcm_gemm_lds_pad,
                            stream,
