@@ -44,6 +44,7 @@ SEQ_LEN = 120
 LR = 5e-4
 KL_GROWTH = 0.003
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md, dense bf16 matrix peak
 
 
 def parse():
@@ -60,6 +61,12 @@ def parse():
                          '~N(60,20) clipped to [10,120] (tokens/s counts the '
                          'real tokens); the default is the fixed-length '
                          'padded batch BASELINE.json names')
+    ap.add_argument('--precision', choices=['fp32', 'bf16'], default='fp32',
+                    help='fp32: the headline line (the only mode parity is '
+                         'claimed on); bf16: a SEPARATE line with dtype '
+                         '"bf16": bf16-rounded MFMA operands in the cells and '
+                         'the recurrent weight gradients, fp32 accumulation, '
+                         'state and optimizer')
     ap.add_argument('--probe', type=int, default=1,
                     help='1: per-kernel launch durations from extra untimed '
                          'steps after the timed region (roofline); 0: off')
@@ -222,6 +229,9 @@ def main():
     # flat bucket (tests/test_gpu_parity.py: test_flat_adam_matches_torch_adam)
     optimizer = dp.FlatAdam(buckets, lr=LR)
     lib = _lib.load()
+    P.set_matmul_precision(args.precision)
+    bf16 = args.precision == 'bf16'
+    mfma_peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
 
     def step(global_step):
         buckets.zero_grad()
@@ -305,7 +315,7 @@ def main():
                 achieved = work / avg_s / 1e12
             else:
                 achieved = work / avg_s / 1e9
-            peak = PEAK_FP32_MFMA_TFLOPS if bound == 'mfma' else PEAK_HBM_GBS
+            peak = mfma_peak if bound == 'mfma' else PEAK_HBM_GBS
             entries.append({
                 'bound': bound, 'kernel': name, 'achieved': achieved,
                 'peak': peak, 'unit': 'TFLOP/s' if bound == 'mfma' else 'GB/s',
@@ -326,8 +336,8 @@ def main():
         step_tflops = value * 29.8e6 / 1e12
         step_roofline = {
             'bound': 'mfma', 'achieved': step_tflops,
-            'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': step_tflops / PEAK_FP32_MFMA_TFLOPS,
+            'peak': mfma_peak, 'unit': 'TFLOP/s',
+            'frac': step_tflops / mfma_peak,
             'note': 'whole step: tokens/s x 29.8 MFLOP per token (SURVEY 8d)',
         }
         cpu = None
@@ -339,14 +349,20 @@ def main():
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32',
+            'data': 'synthetic',
             'config': {
                 'workload': 'Stack-GRU VAE training step (fwd+bwd+Adam), '
                             f'batch {args.batch}/GPU, seq len {SEQ_LEN}, '
                             'vocab 60 one-hot, H=512, L=2, stack 50x50, '
                             'latent 256, dropout 0.2, ' +
                             ('packed mode, ragged lengths ~N(60,20) in '
-                             '[10,120]' if args.ragged else 'padded mode'),
+                             '[10,120]' if args.ragged else 'padded mode') +
+                            ('; MIXED PRECISION (not the headline, no parity '
+                             'claim): bf16-rounded operands on bf16 MFMAs in '
+                             'the GRU cells and recurrent weight gradients, '
+                             'fp32 accumulation / state / optimizer'
+                             if bf16 else ''),
                 'global_batch': world * args.batch, 'seq_len': SEQ_LEN,
                 'parallelism': f'dp{world}',
             },

@@ -80,6 +80,20 @@ const char *pcm_last_error(void);
 int pcm_device_check(void);
 
 /*
+ * Mixed-precision switch (the reference's counterpart is running the model under
+ * torch autocast, which it never does: models/training.py:132-157 trains in
+ * fp32).  mode 0 (default): every product on fp32 MFMAs -- the only mode parity
+ * with the reference is claimed on.  mode 1: the GRU cells' products of the
+ * forward and reverse recurrence and the recurrent weight-gradient GEMMs round
+ * their operands to bf16 (nearest even) and accumulate in fp32 on bf16 MFMAs;
+ * hidden state, gates, stack, output layer, losses and optimizer stay fp32.
+ * Process-wide; set it between calls, not while a call is being enqueued.
+ * Returns PCM_EINVAL for any other mode.  pcm_get_matmul_precision reads it.
+ */
+int pcm_set_matmul_precision(int32_t mode);
+int pcm_get_matmul_precision(void);
+
+/*
  * Measurement aid (no counterpart in the reference): while enabled for one
  * kernel id, each launch of that kernel is made with a (start, stop) event
  * pair bound to the kernel's own dispatch (hipExtLaunchKernelGGL), so the

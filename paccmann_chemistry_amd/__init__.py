@@ -14,5 +14,6 @@ from .stack_rnn import StackGRU  # noqa: F401
 from .vae import StackGRUDecoder, StackGRUEncoder, TeacherVAE  # noqa: F401
 from .loss_functions import vae_loss_function  # noqa: F401
 from .search import BeamSearch, GreedySearch, SamplingSearch  # noqa: F401
+from .ops import get_matmul_precision, set_matmul_precision  # noqa: F401
 
 __version__ = '0.1.0'

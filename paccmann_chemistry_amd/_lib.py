@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get(
     'PCM_LIBRARY', os.path.join(_HERE, 'libpaccmann_hip.so')
 )
 PCM_MAX_LAYERS = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 SEARCH_GREEDY = 0
 SEARCH_SAMPLING = 1
@@ -56,6 +56,8 @@ PROTOTYPES = {
     'pcm_last_error': (ctypes.c_char_p, []),
     'pcm_device_check': (ctypes.c_int, []),
     'pcm_probe_enable': (ctypes.c_int, [_I32, _I32]),
+    'pcm_set_matmul_precision': (ctypes.c_int, [_I32]),
+    'pcm_get_matmul_precision': (ctypes.c_int, []),
     'pcm_probe_calibrate': (
         ctypes.c_int, [
             _I32, ctypes.POINTER(ctypes.c_double),

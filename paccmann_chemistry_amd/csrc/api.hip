@@ -44,6 +44,10 @@ int pcm_check_launch(const char *what) {
 // ---- launch-duration probe ----------------------------------------------------------
 #include <vector>
 int g_pcm_probe_id = 0;
+int g_pcm_matmul_bf16 = [] {
+    const char *e = getenv("PCM_BF16");
+    return (e && atoi(e) == 1) ? 1 : 0;
+}();
 hipEvent_t g_pcm_probe_start = nullptr, g_pcm_probe_stop = nullptr;
 static std::vector<hipEvent_t> g_probe_ev;   // pairs: start, stop
 static size_t g_probe_used = 0;              // events handed out
@@ -401,7 +405,17 @@ static int check_active_rows(const int32_t *active_rows, const int32_t *lengths,
 
 extern "C" {
 
-int pcm_version(void) { return 3; }
+int pcm_version(void) { return 4; }
+
+int pcm_set_matmul_precision(int32_t mode) {
+    PCM_REQUIRE(mode == 0 || mode == 1, PCM_EINVAL,
+                "set_matmul_precision: mode %d (0 = fp32, 1 = bf16 operands)",
+                (int)mode);
+    g_pcm_matmul_bf16 = mode;
+    return PCM_OK;
+}
+
+int pcm_get_matmul_precision(void) { return g_pcm_matmul_bf16; }
 
 int pcm_probe_enable(int32_t kernel_id, int32_t max_launches) {
     PCM_REQUIRE((kernel_id >= 0 && kernel_id <= PCM_K_DW_GEMM) ||

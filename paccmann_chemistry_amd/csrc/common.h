@@ -9,6 +9,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define PCM_WAVE 64
 
@@ -147,7 +149,20 @@ int pcm_launch_beam_backtrack(const int32_t *hist_tok,
                               int64_t *beams_out, double *scores_out,
                               hipStream_t stream);
 
+// ---- mixed-precision mode (pcm_set_matmul_precision) ------------------------------
+// 0: every product on fp32 MFMAs (the default and the only mode parity is claimed
+// on); 1: the recurrent cells' products (forward and reverse) and the weight-
+// gradient GEMM round their operands to bf16 in registers and run on
+// v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16 with fp32 accumulation; state, gates,
+// stack, losses and the optimizer stay fp32.
+extern int g_pcm_matmul_bf16;
+
 // ---- device helpers -------------------------------------------------------------
+// eight fp32 values -> one bf16 MFMA operand fragment (v_cvt_pk_bf16_f32, RNE)
+__device__ __forceinline__ bf16x8 pcm_pack_bf16(f32x4 a, f32x4 b) {
+    f32x8 v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_convertvector(v, bf16x8);
+}
 // n / d for 0 <= n < 2^20 through a float reciprocal (3 VALU instead of ~35):
 // n + 0.5 is never within 0.5 of a multiple of d, far above fp32 rounding.
 __device__ __forceinline__ int pcm_fdiv(int n, float inv_d) {

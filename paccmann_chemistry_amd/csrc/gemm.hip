@@ -193,7 +193,10 @@ struct TileMap {
 
 // FIXED_MODE 0: every problem of the batch is wide (the wave mapping folds at
 // compile time: fewer registers, 3 waves per SIMD); -1: chosen per problem.
-template <int FIXED_MODE>
+// BF16: operands rounded to bf16 in registers, one v_mfma_f32_32x32x16_bf16 per
+// sub-tile and chunk (lane half lk holds k = lk, lk + 2, ... of the chunk for
+// both operands); the column sums stay fp32 sums of the unrounded values.
+template <int FIXED_MODE, bool BF16 = false>
 __global__ __launch_bounds__(256, FIXED_MODE == 0 ? 3 : 2) void gemm_tn_kernel(GemmBatch batch,
                                                          int splits, float *slab,
                                                          SlabInfo slabs,
@@ -273,7 +276,32 @@ __global__ __launch_bounds__(256, FIXED_MODE == 0 ? 3 : 2) void gemm_tn_kernel(G
         auto compute = [&](int buf) {
             const float *as = &As[buf][lk * TN_LD + rbase + lrow];
             const float *bs = &Bs[buf][lk * TN_LD + cbase + lrow];
-            if (mode == 0) {
+            if constexpr (BF16) {
+                f32x8 a0, a1, b0, b1;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    a0[i] = as[2 * i * TN_LD];
+                    b0[i] = bs[2 * i * TN_LD];
+                    cs0 += a0[i];
+                    if (mode != 1) { a1[i] = as[2 * i * TN_LD + 32]; cs1 += a1[i]; }
+                    if (mode != 2) b1[i] = bs[2 * i * TN_LD + 32];
+                }
+                const bf16x8 pa0 = __builtin_convertvector(a0, bf16x8);
+                const bf16x8 pb0 = __builtin_convertvector(b0, bf16x8);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, pb0, acc[0][0], 0, 0, 0);
+                if (mode != 2) {
+                    const bf16x8 pb1 = __builtin_convertvector(b1, bf16x8);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa0, pb1, acc[0][1], 0, 0, 0);
+                    if (mode == 0) {
+                        const bf16x8 pa1 = __builtin_convertvector(a1, bf16x8);
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, pb0, acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, pb1, acc[1][1], 0, 0, 0);
+                    }
+                } else {
+                    const bf16x8 pa1 = __builtin_convertvector(a1, bf16x8);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa1, pb0, acc[1][0], 0, 0, 0);
+                }
+            } else if (mode == 0) {
 #pragma unroll
                 for (int kk = 0; kk < BK; kk += 2) {
                     const float a0 = as[kk * TN_LD], a1 = as[kk * TN_LD + 32];
@@ -580,7 +608,11 @@ int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
         // the weight-gradient probe (id 6) times the wide launches only (a
         // cleared start event makes pcm_probe_end_ drop the pair)
         if (!wide && g_pcm_probe_id == PCM_K_DW_GEMM) g_pcm_probe_start = nullptr;
-        if (wide)
+        if (wide && g_pcm_matmul_bf16)
+            PCM_LAUNCH((gemm_tn_kernel<0, true>), tn_grid, dim3(256),
+                               g_pcm_gemm_lds_pad, stream, batch, pl.splits,
+                               slab, slabs, tmap);
+        else if (wide)
             PCM_LAUNCH(gemm_tn_kernel<0>, tn_grid, dim3(256),
                                g_pcm_gemm_lds_pad, stream, batch, pl.splits,
                                slab, slabs, tmap);

@@ -391,7 +391,7 @@ __device__ __forceinline__ void raw_barrier() {
 // ct) adds, after its own K loop, the product of K part ct / ncx and input-side
 // column tile ct % ncx (ncx = Kxp / 32) in a second accumulator and stores it
 // as partial number ct / ncx; the stack adjoint sums the partials in order.
-template <int BCN, int BNSTAGE, bool XPART = false>
+template <int BCN, int BNSTAGE, bool XPART = false, bool BF16 = false>
 __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
     static_assert(!XPART || BCN == 32, "XPART rides on the narrow tile");
     constexpr int BSTAGE = (BCM + BCN) * BCK;    // floats per LDS stage
@@ -558,6 +558,16 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
             }
             if constexpr (BNSTAGE < 3)
                 raw_barrier();   // B_c (waits for the fragment reads first)
+            if constexpr (BF16) {
+                // the lane's eight k of the chunk slice as one bf16 fragment
+                const bf16x8 ba = pcm_pack_bf16(fa[0], fa[1]);
+                acc_main = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    ba, pcm_pack_bf16(f0[0], f0[1]), acc_main, 0, 0, 0);
+                if constexpr (BCN == 64)
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                        ba, pcm_pack_bf16(f1[0], f1[1]), acc1, 0, 0, 0);
+                return;
+            }
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -732,6 +742,18 @@ int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream) {
     b.reg_cols = (nct + 3) / 4;
     b.reg_rows = (nbt + 1) / 2;
     dim3 grid(8 * b.reg_cols * b.reg_rows);
+    if (g_pcm_matmul_bf16) {
+        if (xpart)
+            PCM_LAUNCH((gru_cell_bwd_kernel<32, 3, true, true>), grid, dim3(512),
+                       0, stream, b);
+        else if (narrow)
+            PCM_LAUNCH((gru_cell_bwd_kernel<32, 3, false, true>), grid,
+                       dim3(512), 0, stream, b);
+        else
+            PCM_LAUNCH((gru_cell_bwd_kernel<64, 2, false, true>), grid,
+                       dim3(512), 0, stream, b);
+        return 0;
+    }
     if (xpart)
         PCM_LAUNCH((gru_cell_bwd_kernel<32, 3, true>), grid, dim3(512), 0,
                            stream, b);

@@ -170,6 +170,7 @@ __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
 constexpr int CNSTAGE = 2;
 static_assert(CNSTAGE * GSTAGE >= 4 * 4 * 1024, "reduction buffer must fit");
 
+template <bool BF16>
 __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[CNSTAGE * GSTAGE];
     const int tid = threadIdx.x;
@@ -250,6 +251,18 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
                 fn[s] = *(const f32x4 *)(As + (CM + 2 * CN) * CK + slot[s]);
             }
             raw_barrier();   // B_c (waits for the fragment reads first)
+            if constexpr (BF16) {
+                // the lane's eight k of the chunk slice as ONE bf16 fragment
+                // (any lane -> k map serves as long as both operands share it)
+                const bf16x8 ba = pcm_pack_bf16(fa[0], fa[1]);
+                acc_r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    ba, pcm_pack_bf16(fr[0], fr[1]), acc_r, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    ba, pcm_pack_bf16(fz[0], fz[1]), acc_z, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    ba, pcm_pack_bf16(fn[0], fn[1]), acc_n, 0, 0, 0);
+                return;
+            }
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -318,6 +331,7 @@ __device__ __forceinline__ void glds5(const char *const (&base)[5],
         : "memory", "scc");
 }
 
+template <bool BF16>
 __global__ __launch_bounds__(512) void gru_cell_fwd16_kernel(CellFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[NNSTAGE * NSTAGE];
     const int tid = threadIdx.x;
@@ -409,6 +423,16 @@ __global__ __launch_bounds__(512) void gru_cell_fwd16_kernel(CellFwdArgs a) {
                 fn[s] = *(const f32x4v *)(As + 2 * NCN * CK + slot_w[s]);
             }
             raw_barrier();   // B_c (waits for the fragment reads first)
+            if constexpr (BF16) {
+                const bf16x8 ba = pcm_pack_bf16(fa[0], fa[1]);
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    ba, pcm_pack_bf16(fr[0], fr[1]), acc_r, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    ba, pcm_pack_bf16(fz[0], fz[1]), acc_z, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    ba, pcm_pack_bf16(fn[0], fn[1]), acc_n, 0, 0, 0);
+                return;
+            }
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -1061,10 +1085,16 @@ int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
     const bool narrow = force ? force == 16 : load_narrow < load_wide;
     if (narrow) {
         dim3 grid(a.Hn / NCN, nbt);
-        PCM_LAUNCH(gru_cell_fwd16_kernel, grid, dim3(512), 0, stream, a);
+        if (g_pcm_matmul_bf16)
+            PCM_LAUNCH(gru_cell_fwd16_kernel<true>, grid, dim3(512), 0, stream, a);
+        else
+            PCM_LAUNCH(gru_cell_fwd16_kernel<false>, grid, dim3(512), 0, stream, a);
     } else {
         dim3 grid(a.Hn / CN, nbt);
-        PCM_LAUNCH(gru_cell_fwd_kernel, grid, dim3(512), 0, stream, a);
+        if (g_pcm_matmul_bf16)
+            PCM_LAUNCH(gru_cell_fwd_kernel<true>, grid, dim3(512), 0, stream, a);
+        else
+            PCM_LAUNCH(gru_cell_fwd_kernel<false>, grid, dim3(512), 0, stream, a);
     }
     return 0;
 }

@@ -11,6 +11,29 @@ from . import _lib
 from ._lib import check, load, ptr, require_device, stream_ptr
 
 
+_PRECISIONS = {'fp32': 0, 'bf16': 1}
+
+
+def set_matmul_precision(precision):
+    """'fp32' (default; the mode parity with the reference is claimed on) or
+    'bf16': the recurrent cells' products and the recurrent weight gradients
+    take bf16-rounded operands with fp32 accumulation (pcm_set_matmul_precision).
+    The reference trains in fp32 only (models/training.py:132-157)."""
+    if precision not in _PRECISIONS:
+        raise ValueError(
+            f'precision {precision!r}: expected one of {sorted(_PRECISIONS)}'
+        )
+    check(
+        load().pcm_set_matmul_precision(_PRECISIONS[precision]),
+        'set_matmul_precision'
+    )
+
+
+def get_matmul_precision():
+    mode = load().pcm_get_matmul_precision()
+    return next(k for k, v in _PRECISIONS.items() if v == mode)
+
+
 def _f32(t, what):
     require_device(t, what)
     if t.dtype != torch.float32:
