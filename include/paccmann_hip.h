@@ -262,6 +262,26 @@ int pcm_softmax_ce(const float *logits, const int64_t *targets,
                    float *scratch, int32_t *status, void *stream);
 
 /*
+ * Output layer fused with the cross entropy: logits = x . w^T + bias
+ * (output_layer, vae.py:342) and, in the same kernel, the per-step criterion
+ * and the monitoring argmax (vae.py:343-348, 386-388) -- the logits do not
+ * travel through memory between the two.
+ *
+ *   x        fp32 rows [T*B] of `hidden` floats, row stride ldx
+ *   w, bias  output_layer.weight [V,H], .bias [V]
+ *   logits   fp32[T,B,V] (nullable: not written; required for shapes outside
+ *            the fused kernel -- V > 128, H not a multiple of 8, rows not
+ *            16-byte aligned --, which run as pcm_linear_forward + pcm_softmax_ce)
+ *   everything else as pcm_softmax_ce
+ */
+int pcm_output_ce(const float *x, int64_t ldx, const float *w,
+                  const float *bias, const int64_t *targets,
+                  const int32_t *lengths, const float *step_weight,
+                  int32_t steps, int32_t batch, int32_t vocab, int32_t hidden,
+                  float *logits, float *loss, int64_t *argmax, float *dlogits,
+                  float *scratch, int32_t *status, void *stream);
+
+/*
  * pcm_softmax_ce for callers that cannot allocate device memory (code under
  * HIP graph capture, tight serving / evaluation loops, harnesses that forbid
  * hipMalloc).  NO counterpart in the reference: the same computation with the

@@ -102,6 +102,11 @@ PROTOTYPES = {
         ctypes.c_int,
         [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP]
     ),
+    'pcm_output_ce': (
+        ctypes.c_int,
+        [_VP, _I64, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP,
+         _VP, _VP, _VP, _VP, _VP]
+    ),
     'pcm_softmax_ce_static': (
         ctypes.c_int,
         [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP]

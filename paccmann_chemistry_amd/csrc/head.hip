@@ -86,6 +86,157 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(
     }
 }
 
+// ---- output layer fused with the cross entropy ----------------------------------
+// logits = x . W^T + b on fp32 MFMAs and, without a round trip of the logits
+// through memory, the row's softmax / cross entropy / first-maximum argmax and
+// d loss / d logits (vae.py:342-348, 386-388).  One wave owns 64 rows (two 32-row
+// MFMA tiles) x all V <= 32 NT columns over the whole K, so a logit is one
+// in-order accumulation chain; operand fragments are 16-byte global loads (lane
+// half lk holds k = 8 g + 4 lk + e of k group g for both operands), the weights
+// (V x H, L2-resident) are shared by every wave.  The finished tile is parked in
+// LDS: lane r reduces row r, then the wave writes logits and dlogits as one
+// contiguous, lane-linear range.
+struct OutputCeArgs {
+    const float *x;          // [rows][ldx]
+    long long ldx;
+    const float *w;          // [V][H]
+    const float *bias;       // [V]
+    const int64_t *targets;  // [rows]
+    const int32_t *lengths;  // [B] or null
+    const float *inv_cnt;    // [T]
+    float *logits;           // [rows][V] or null
+    float *rowloss;          // [rows]
+    int64_t *argmax;         // [B][T] or null
+    float *dlogits;          // [rows][V] or null
+    int32_t *status;
+    long long rows;
+    int T, B, V, H;
+    float inv_v;
+};
+
+constexpr int OC_ROWS = 64;   // rows per wave
+
+template <int NT>
+__global__ __launch_bounds__(256) void output_ce_kernel(OutputCeArgs a) {
+    constexpr int LD = NT * 32 + 1;
+    extern __shared__ float oc_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lrow = lane & 31, lk = lane >> 5;
+    const long long row0 = ((long long)blockIdx.x * 4 + wave) * OC_ROWS;
+    if (row0 >= a.rows) return;   // (no block-wide barrier below)
+    float *tile = oc_lds + wave * (OC_ROWS * LD + 3 * OC_ROWS);
+    float *lse_s = tile + OC_ROWS * LD;
+    float *w_s = lse_s + OC_ROWS;
+    int *tg_s = (int *)(w_s + OC_ROWS);
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const float *xa[2], *wb[NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        long long r = row0 + 32 * i + lrow;
+        if (r > a.rows - 1) r = a.rows - 1;   // re-read the last row, masked below
+        xa[i] = a.x + r * a.ldx + 4 * lk;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+        wb[j] = a.w + (long long)min(32 * j + lrow, a.V - 1) * a.H + 4 * lk;
+    // fragments of the next k group are requested before this group's MFMAs
+    // (the last iteration re-reads its own group)
+    f32x4 fa[2], fb[NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[i] = *(const f32x4 *)(xa[i]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[j] = *(const f32x4 *)(wb[j]);
+    for (int kb = 0; kb < a.H; kb += 8) {
+        const int kn = min(kb + 8, a.H - 8);
+        f32x4 na[2], nb[NT];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) na[i] = *(const f32x4 *)(xa[i] + kn);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) nb[j] = *(const f32x4 *)(wb[j] + kn);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = na[i];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j] = nb[j];
+    }
+    // park logits (+ bias) in LDS: lane holds column lrow of tile j, rows
+    // (r & 3) + 8 (r >> 2) + 4 lk of tile i
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = 32 * j + lrow;
+        const float bv = col < a.V ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                tile[row * LD + col] = acc[i][j][r] + bv;
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // lane r: softmax statistics of row r
+    const long long row = row0 + lane;
+    const int V = a.V;
+    if (row < a.rows) {
+        const int t = (int)(row / a.B), b = (int)(row - (long long)t * a.B);
+        const bool active = !a.lengths || t < a.lengths[b];
+        const float *x = tile + lane * LD;
+        float m = -INFINITY;
+        int mi = 0;
+        for (int v = 0; v < V; ++v) {
+            const float xv = x[v];
+            if (xv > m) { m = xv; mi = v; }   // first maximum
+        }
+        float s = 0.f;
+        for (int v = 0; v < V; ++v) s += expf(x[v] - m);
+        const float lse = m + logf(s);
+        long long tg = a.targets[row];
+        if (active && (tg < 0 || tg >= V)) {
+            tg = tg < 0 ? 0 : V - 1;
+            if (a.status) atomicOr(a.status, PCM_STATUS_BAD_TOKEN);
+        }
+        if (!active) tg = 0;
+        const float w = active ? a.inv_cnt[t] : 0.f;
+        a.rowloss[row] = active ? (lse - x[tg]) * w : 0.f;
+        if (a.argmax) a.argmax[(long long)b * a.T + t] = active ? mi : 0;
+        lse_s[lane] = lse; w_s[lane] = w; tg_s[lane] = active ? (int)tg : -1;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // logits / dlogits of the wave's rows: one contiguous range, lane-linear
+    const long long left = a.rows - row0;
+    const int nrows = left < OC_ROWS ? (int)left : OC_ROWS;
+    const int n = nrows * V;
+    float *lo = a.logits ? a.logits + row0 * V : nullptr;
+    float *dl = a.dlogits ? a.dlogits + row0 * V : nullptr;
+    for (int idx = lane; idx < n; idx += 64) {
+        const int r = pcm_fdiv(idx, a.inv_v), c = idx - r * V;
+        const float xv = tile[r * LD + c];
+        if (lo) lo[idx] = xv;
+        if (dl) {
+            const int tg = tg_s[r];
+            dl[idx] = tg < 0 ? 0.f
+                             : (expf(xv - lse_s[r]) - (c == tg ? 1.f : 0.f)) *
+                                   w_s[r];
+        }
+    }
+}
+
 // deterministic single-block sum of n floats, scaled
 __global__ __launch_bounds__(1024) void sum_kernel(const float *x, long long n,
                                                    float scale, float *out) {
@@ -613,6 +764,70 @@ int pcm_softmax_ce(const float *logits, const int64_t *targets,
     return softmax_ce_enqueue(logits, targets, lengths, step_weight, steps, batch,
                               vocab, loss, argmax, dlogits, scratch, status,
                               (hipStream_t)stream);
+}
+
+int pcm_output_ce(const float *x, int64_t ldx, const float *w,
+                  const float *bias, const int64_t *targets,
+                  const int32_t *lengths, const float *step_weight,
+                  int32_t steps, int32_t batch, int32_t vocab, int32_t hidden,
+                  float *logits, float *loss, int64_t *argmax, float *dlogits,
+                  float *scratch, int32_t *status, void *stream) {
+    PCM_REQUIRE(x && w && bias && targets && loss && scratch, PCM_EINVAL,
+                "output_ce: null pointer");
+    PCM_REQUIRE(steps > 0 && batch > 0 && vocab > 0 && hidden > 0, PCM_EINVAL,
+                "output_ce: bad shape T=%d B=%d V=%d H=%d", steps, batch, vocab,
+                hidden);
+    PCM_REQUIRE(ldx >= hidden, PCM_EINVAL, "output_ce: ldx %lld < H %d",
+                (long long)ldx, hidden);
+    hipStream_t st = (hipStream_t)stream;
+    const long long rows = (long long)steps * batch;
+    const bool fused = vocab <= 128 && hidden % 8 == 0 && ldx % 4 == 0 &&
+                       ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0;
+    if (!fused) {
+        // shapes outside the fused kernel: output layer, then the cross entropy
+        PCM_REQUIRE(logits, PCM_EINVAL,
+                    "output_ce: V=%d H=%d ldx=%lld needs a logits buffer (the "
+                    "fused kernel takes V <= 128, H %% 8 == 0, 16-byte aligned "
+                    "rows)", vocab, hidden, (long long)ldx);
+        PCM_REQUIRE(rows <= 0x7fffffff, PCM_EINVAL, "output_ce: too many rows");
+        int rc = pcm_linear_forward(x, ldx, w, bias, logits, vocab, (int32_t)rows,
+                                    vocab, hidden, stream);
+        if (rc) return rc;
+        return softmax_ce_enqueue(logits, targets, lengths, step_weight, steps,
+                                  batch, vocab, loss, argmax, dlogits, scratch,
+                                  status, st);
+    }
+    float *rowloss = scratch;
+    float *inv_cnt = scratch + rows;
+    hipLaunchKernelGGL(step_count_kernel, dim3((steps + 255) / 256), dim3(256),
+                       0, st, lengths, step_weight, steps, batch, inv_cnt);
+    OutputCeArgs a;
+    a.x = x; a.ldx = ldx; a.w = w; a.bias = bias; a.targets = targets;
+    a.lengths = lengths; a.inv_cnt = inv_cnt; a.logits = logits;
+    a.rowloss = rowloss; a.argmax = argmax; a.dlogits = dlogits;
+    a.status = status; a.rows = rows; a.T = steps; a.B = batch; a.V = vocab;
+    a.H = hidden; a.inv_v = 1.0f / (float)vocab;
+    const int nt = (vocab + 31) / 32;
+    const unsigned blocks = (unsigned)((rows + 4 * OC_ROWS - 1) / (4 * OC_ROWS));
+    const size_t lds = 4 * (size_t)(OC_ROWS * (nt * 32 + 1) + 3 * OC_ROWS) *
+                       sizeof(float);
+    switch (nt) {
+    case 1:
+        hipLaunchKernelGGL(output_ce_kernel<1>, dim3(blocks), dim3(256), lds, st, a);
+        break;
+    case 2:
+        hipLaunchKernelGGL(output_ce_kernel<2>, dim3(blocks), dim3(256), lds, st, a);
+        break;
+    case 3:
+        hipLaunchKernelGGL(output_ce_kernel<3>, dim3(blocks), dim3(256), lds, st, a);
+        break;
+    default:
+        hipLaunchKernelGGL(output_ce_kernel<4>, dim3(blocks), dim3(256), lds, st, a);
+        break;
+    }
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, rowloss, rows,
+                       1.0f, loss);
+    return pcm_check_launch("output_ce");
 }
 
 int pcm_softmax_ce_static(const float *logits, const int64_t *targets,

@@ -339,12 +339,6 @@ class DecoderHeadFn(torch.autograd.Function):
         dev = out.device
         x2, m, ldx = _rows2d(out, 'decoder outputs')
         logits = torch.empty(steps, batch, vocab, device=dev)
-        check(
-            lib.pcm_linear_forward(
-                ptr(x2), ldx, ptr(weight), ptr(bias), ptr(logits), vocab, m,
-                vocab, hid, stream_ptr(dev)
-            ), 'pcm_linear_forward(output_layer)'
-        )
         targets = targets.to(device=dev, dtype=torch.int64).contiguous()
         if lengths is not None:
             lengths = lengths.to(device=dev, dtype=torch.int32).contiguous()
@@ -360,12 +354,14 @@ class DecoderHeadFn(torch.autograd.Function):
             ).contiguous()
             if step_weight.numel() != steps:
                 raise ValueError('step_weight must have one entry per step')
+        # output layer, softmax, cross entropy and argmax in one kernel
         check(
-            lib.pcm_softmax_ce(
-                ptr(logits), ptr(targets), ptr(lengths), ptr(step_weight),
-                steps, batch, vocab, ptr(loss), ptr(argmax), ptr(dlogits),
+            lib.pcm_output_ce(
+                ptr(x2), ldx, ptr(weight), ptr(bias), ptr(targets),
+                ptr(lengths), ptr(step_weight), steps, batch, vocab, hid,
+                ptr(logits), ptr(loss), ptr(argmax), ptr(dlogits),
                 ptr(scratch), ptr(status), stream_ptr(dev)
-            ), 'pcm_softmax_ce'
+            ), 'pcm_output_ce'
         )
         ctx.save_for_backward(x2, weight)
         ctx.dlogits = dlogits

@@ -16,7 +16,9 @@ reference included:
       does (plus 1e-3) -- it stays inside the reference's own rounding envelope;
   (3) over all 1k steps the 50-step window medians stay in a sanity band around
       the fp64 run (factor exp(0.5), or 3x the reference's own fp32 deviation);
-  (4) at the config-shaped model, 60 steps, plain 1e-3 on every step.
+  (4) at the config-shaped model (240 steps in the fixture), plain 1e-3 on every
+      step of the prefix in which the reference agrees with itself (64 steps:
+      its fp32 run is 1e-3 from its fp64 run at step 121), then (2) and (3).
 """
 import os
 
@@ -154,7 +156,28 @@ def test_hip_path_follows_reference_curve_1k_steps():
 @pytest.mark.gpu
 def test_hip_path_follows_reference_curve_config_model():
     name = 'loss_curve_config'
-    ref32, _ = _reference_curve(name)
+    ref32, ref64 = _reference_curve(name)
     curve = _gpu_curve(W.LOSS_CURVES[name])
+    assert curve.shape[0] == ref32.shape[0] >= 240
     assert np.isfinite(curve).all()
-    assert _worst(curve, ref32) < CURVE_TOL, _worst(curve, ref32)
+    # (4) plain 1e-3 on every step up to where the reference's own fp32 run
+    # parts from its fp64 run (step 64 of this protocol; 1e-3 apart at step 121)
+    n0 = _stable_prefix(ref32, ref64)
+    assert n0 >= 60, n0
+    assert _worst(curve[:n0], ref32) < CURVE_TOL, (n0, _worst(curve[:n0], ref32))
+    # then inside the reference's own rounding envelope until its two runs are
+    # 10 % apart ...
+    dev_ref = np.maximum.accumulate(_rel(ref32[:, 0], ref64[:, 0]))
+    dev_hip = np.maximum.accumulate(_rel(curve[:, 0], ref64[:, 0]))
+    n1 = int((dev_ref < 0.1).sum())
+    assert n1 >= n0
+    excess = dev_hip[:n1] - (3.0 * dev_ref[:n1] + CURVE_TOL)
+    assert (excess <= 0).all(), (int(excess.argmax()), excess.max())
+    # ... and over all steps the same sanity band on 40-step window medians as
+    # in the 1k-step test
+    for a in range(0, curve.shape[0], 40):
+        m_hip, m32, m64 = (np.median(x[a:a + 40, 0])
+                           for x in (curve, ref32, ref64))
+        bound = max(3.0 * abs(np.log(m32 / m64)), 0.5)
+        assert abs(np.log(m_hip / m64)) <= bound, (a, m_hip, m32, m64)
+    assert curve[-1, 0] < 0.5 * curve[0, 0]
