@@ -488,6 +488,155 @@ __global__ __launch_bounds__(512) void gru_cell_fwd16_kernel(CellFwdArgs a) {
 }
 
 // ------------------------------------------------------------------------------
+// large-batch fused GRU cell: 64 batch rows x 64 hidden units per block
+// ------------------------------------------------------------------------------
+// With thousands of rows every CU gets several blocks, so what counts is MFMA
+// time over block time.  Here consumer wave (rh, ch) owns the 32-row x 32-unit
+// quadrant (rh, ch) of the tile over the WHOLE K -- no split-K, no cross-wave
+// reduction, gate math straight from the accumulators --, and one block does
+// four times the MFMA work of the 32 x 32 tile per prologue / epilogue and
+// stages half the bytes per FLOP.  K chunks are 32 wide (two 32 KiB stages, so
+// two blocks share a CU and fill each other's barrier waits): a DMA instruction
+// fills 8 rows of 128 bytes, granule g of row r sits in slot g ^ ((r >> 1) & 7)
+// (rows r, r + 1 are half a bank sweep apart), conflict-free for the 16-lane
+// passes of the ds_read_b128 fragment reads.
+constexpr int LM = 64, LN = 64, LK = 32;
+constexpr int LROWS = LM + 3 * LN;     // stage rows (256)
+constexpr int LSTAGE = LROWS * LK;     // floats per stage (32 KiB)
+
+template <bool BF16>
+__global__ __launch_bounds__(512, 4) void gru_cell_fwd64_kernel(CellFwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * LSTAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j0 = blockIdx.x * LN;
+    const int b0 = blockIdx.y * LM;
+    const int nx = 2 * a.nx_chunks;               // 32-wide chunks
+    const int nchunks = nx + 2 * a.nh_chunks;
+    const int last = nchunks - 1;
+    const int lrow = lane & 31, lh = lane >> 5;
+
+    if (wave >= 4) {
+        // loaders: wave lw fills stage rows 64 lw .. 64 lw + 63 (lw 0: the
+        // activation rows; 1-3: the r, z, n weight rows of the 64 hidden units)
+        // with 8 DMA instructions of 8 rows each
+        const int lw = wave - 4;
+        const char *xb = (const char *)a.xin, *hb = (const char *)a.hprev;
+        const char *wb = (const char *)a.wpack;
+        uint32_t off0[8], off1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 8 * (lw * 8 + i) + (lane >> 3);
+            const int g = (lane & 7) ^ ((row >> 1) & 7);
+            if (lw == 0) {
+                const int b = min(b0 + row, a.B - 1);
+                off0[i] = (uint32_t)(b * a.ldx + g * 4) * 4u;
+                off1[i] = (uint32_t)(b * a.Hp + g * 4) * 4u;
+            } else {
+                const int jj = row & 63;
+                off0[i] =
+                    (uint32_t)(((lw - 1) * a.Hn + j0 + jj) * a.Kp + g * 4) * 4u;
+                off1[i] = 0;
+            }
+        }
+        const uint32_t lds0 = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(size_t)(__attribute__((address_space(3))) void *)lds);
+        auto issue = [&](int cc) {
+            const int c = min(cc, last);
+            const uint32_t dst = lds0 + ((cc & 1) * LSTAGE + lw * 64 * LK) * 4u;
+            if (lw == 0) {
+                if (c < nx)
+                    glds8(xb + c * (LK * 4), off0, dst);
+                else
+                    glds8(hb + (c - nx) * (LK * 4), off1, dst);
+            } else {
+                glds8(wb + c * (LK * 4), off0, dst);
+            }
+        };
+        issue(0); issue(1);
+        for (int k = 0; k < nchunks; ++k) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // chunk k landed
+            raw_barrier();   // A_k: the consumers may read chunk k
+            raw_barrier();   // B_k: they hold its fragments, the stage is free
+            issue(k + 2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    f32x16 acc_r, acc_z, acc_ni, acc_nh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc_r[r] = 0.f; acc_z[r] = 0.f; acc_ni[r] = 0.f; acc_nh[r] = 0.f;
+    }
+    const int rh = wave & 1, ch = wave >> 1;
+    // k group q (8 wide) of a chunk = granules 4 q + lh + 2 s (s = 0, 1) of the
+    // lane's activation row and of its weight row of every gate; every such
+    // row r has ((r >> 1) & 7) == ((lrow >> 1) & 7)
+    const int sw = (lrow >> 1) & 7;
+    int slot[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            slot[2 * q + s] = ((4 * q + lh + 2 * s) ^ sw) << 2;
+    const int row_a = (32 * rh + lrow) * LK;
+    const int row_w = (LM + 32 * ch + lrow) * LK;
+    auto chunk = [&](int c, f32x16 &acc_n) {
+        f32x4 fa[4], fr[4], fz[4], fn[4];
+        raw_barrier();   // A_c
+        const float *As = lds + (c & 1) * LSTAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i] = *(const f32x4 *)(As + row_a + slot[i]);
+            fr[i] = *(const f32x4 *)(As + row_w + slot[i]);
+            fz[i] = *(const f32x4 *)(As + LN * LK + row_w + slot[i]);
+            fn[i] = *(const f32x4 *)(As + 2 * LN * LK + row_w + slot[i]);
+        }
+        raw_barrier();   // B_c (waits for the fragment reads first)
+        if constexpr (BF16) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bf16x8 ba = pcm_pack_bf16(fa[2 * q], fa[2 * q + 1]);
+                acc_r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    ba, pcm_pack_bf16(fr[2 * q], fr[2 * q + 1]), acc_r, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    ba, pcm_pack_bf16(fz[2 * q], fz[2 * q + 1]), acc_z, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    ba, pcm_pack_bf16(fn[2 * q], fn[2 * q + 1]), acc_n, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc_r = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[i][e], fr[i][e], acc_r, 0, 0, 0);
+                    acc_z = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[i][e], fz[i][e], acc_z, 0, 0, 0);
+                    acc_n = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                        fa[i][e], fn[i][e], acc_n, 0, 0, 0);
+                }
+        }
+    };
+    for (int c = 0; c < nx; ++c) chunk(c, acc_ni);
+    for (int c = nx; c < nchunks; ++c) chunk(c, acc_nh);
+
+    // gate math straight from the accumulators: lane = hidden unit, register r =
+    // batch row (r & 3) + 8 (r >> 2) + 4 lh of the quadrant
+    const int j = j0 + 32 * ch + lrow;
+    if (j >= a.H) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int b = b0 + 32 * rh + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (b >= a.B) continue;
+        const float s[4] = {acc_r[r], acc_z[r], acc_ni[r], acc_nh[r]};
+        cell_fwd_element(a, b, j, s);
+    }
+}
+
+// ------------------------------------------------------------------------------
 // stack controls + fused stack update
 // ------------------------------------------------------------------------------
 // One block of 512 threads per SROWS batch rows.  The rows' previous stacks are
@@ -888,7 +1037,7 @@ __global__ __launch_bounds__(512) void stack_step_fwd_mfma_kernel(StackFwdArgs a
     }
     // the update, four consecutive elements per thread (DW % 4 == 0)
     const int nq = DW >> 2;
-    const float inv_nq = 1.0f / (float)nq, inv_W = 1.0f / (float)W;
+    const float inv_nq = 1.0f / (float)nq;
 #pragma unroll 4
     for (int idx = tid; idx < MROWS * nq; idx += 512) {
         const int r = pcm_fdiv(idx, inv_nq), q = idx - r * nq;
@@ -929,7 +1078,7 @@ __global__ __launch_bounds__(512) void stack_step_fwd_mfma_kernel(StackFwdArgs a
         const int r = idx / padw, w = W + idx - r * padw;
         if (b0 + r < a.B) a.xtop[(long long)(b0 + r) * a.Wp + w] = 0.f;
     }
-    (void)D; (void)inv_W;
+    (void)D;
 }
 
 // ------------------------------------------------------------------------------
@@ -1082,6 +1231,16 @@ int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
     const int wide_tiles = (a.Hn / CN) * nbt;
     const float load_wide = 2.0f * ((wide_tiles + cus - 1) / cus);
     const float load_narrow = 1.06f * ((2 * wide_tiles + cus - 1) / cus);
+    // thousands of rows: 64 x 64 tiles (see the kernel)
+    const bool big = (force ? force == 64 : a.B >= 2048) && (a.Hn % LN) == 0;
+    if (big) {
+        dim3 grid(a.Hn / LN, (a.B + LM - 1) / LM);
+        if (g_pcm_matmul_bf16)
+            PCM_LAUNCH(gru_cell_fwd64_kernel<true>, grid, dim3(512), 0, stream, a);
+        else
+            PCM_LAUNCH(gru_cell_fwd64_kernel<false>, grid, dim3(512), 0, stream, a);
+        return 0;
+    }
     const bool narrow = force ? force == 16 : load_narrow < load_wide;
     if (narrow) {
         dim3 grid(a.Hn / NCN, nbt);

@@ -962,6 +962,7 @@ def test_prepare_batch_on_device_bernoulli():
     {'PCM_BWD_TILE': '64', 'PCM_FWD_TILE': '32', 'PCM_STACK_LEAN': '0'},
     {'PCM_FWD_TILE': '16', 'PCM_BWD_XPART': '0', 'PCM_STACK_LEAN': '1'},
     {'PCM_FUSED_CHOOSE': '0', 'PCM_STACK_MFMA': '1'},
+    {'PCM_FWD_TILE': '64'},
 ])
 def test_alternate_kernel_variants(env):
     """The launchers pick tile widths / kernel variants by shape; the variants
@@ -969,7 +970,8 @@ def test_alternate_kernel_variants(env):
     forward tiles, lean / prefetching / MFMA stack step, plain layer-0 reverse cell,
     two-launch output layer + search) are forced through their environment
     switches -- read once per process, hence a child process -- over the
-    config-shaped, packed and greedy-decode fixtures."""
+    config-shaped, packed and greedy-decode fixtures (PCM_FWD_TILE=64: the
+    large-batch 64 x 64 forward tile on small ragged batches)."""
     import os
     import subprocess
     import sys
