@@ -79,23 +79,52 @@ class StackGRUEncoder(StackGRU):
         tokens, lengths = packed_to_lengths(input_seq)
         return self._encode(tokens, lengths, hidden, stack)
 
+    # The reversed-time recurrence (vae.py:118-135, 186-235) is independent of
+    # the forward-time one until the concat: on a GPU it is enqueued on a second
+    # stream, so the two launch chains interleave on the chip (autograd replays
+    # each on the stream it ran on).  False: one after the other.
+    concurrent_directions = True
+
     def _encode(self, tokens, lengths, hidden, stack):
         h0, s0 = self._initial(hidden, stack, self)
-        _, h_final, _ = self._run_sequence(tokens, lengths, h0, s0)
-        hidden = self._post_gru_reshape(h_final)
+        side = None
         if self.bidirectional:
             assert len(tokens.shape) == 2, 'Input Seq must be 2D Tensor.'
             if lengths is None:
                 rev = torch.flip(tokens, dims=[0])
             else:
                 rev = _reverse_within_length(tokens, lengths)
-            _, h_back, _ = self.backward_stackgru._run_sequence(
-                rev, lengths, None, None
-            )
+            if tokens.is_cuda and self.concurrent_directions:
+                main = torch.cuda.current_stream(tokens.device)
+                side = self._direction_stream(tokens.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    _, h_back, _ = self.backward_stackgru._run_sequence(
+                        rev, lengths, None, None
+                    )
+        _, h_final, _ = self._run_sequence(tokens, lengths, h0, s0)
+        hidden = self._post_gru_reshape(h_final)
+        if self.bidirectional:
+            if side is None:
+                _, h_back, _ = self.backward_stackgru._run_sequence(
+                    rev, lengths, None, None
+                )
+            else:
+                main.wait_stream(side)
+                # allocated on the side stream, read on this one from here on
+                h_back.record_stream(main)
+                rev.record_stream(side)
             hidden = torch.cat(
                 [hidden, self._post_gru_reshape(h_back)], axis=1
             )
         return hidden
+
+    def _direction_stream(self, device):
+        streams = self.__dict__.setdefault('_direction_streams', {})
+        key = (device.type, device.index)
+        if key not in streams:
+            streams[key] = torch.cuda.Stream(device=device)
+        return streams[key]
 
     def _post_gru_reshape(self, hidden: torch.Tensor) -> torch.Tensor:
         """vae.py:238-249."""
