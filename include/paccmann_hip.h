@@ -270,8 +270,8 @@ int pcm_softmax_ce(const float *logits, const int64_t *targets,
  *   x        fp32 rows [T*B] of `hidden` floats, row stride ldx
  *   w, bias  output_layer.weight [V,H], .bias [V]
  *   logits   fp32[T,B,V] (nullable: not written; required for shapes outside
- *            the fused kernel -- V > 128, H not a multiple of 8, rows not
- *            16-byte aligned --, which run as pcm_linear_forward + pcm_softmax_ce)
+ *            the fused kernel -- V > 128 or H not a multiple of 8 --, which run
+ *            as pcm_linear_forward + pcm_softmax_ce)
  *   everything else as pcm_softmax_ce
  */
 int pcm_output_ce(const float *x, int64_t ldx, const float *w,

@@ -115,6 +115,9 @@ struct OutputCeArgs {
 };
 
 constexpr int OC_ROWS = 64;   // rows per wave
+// operands may sit at any 4-byte boundary (parameters that live inside a flat
+// optimizer buffer): global_load_dwordx4 takes dword-aligned addresses
+typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 template <int NT>
 __global__ __launch_bounds__(256) void output_ce_kernel(OutputCeArgs a) {
@@ -150,16 +153,16 @@ __global__ __launch_bounds__(256) void output_ce_kernel(OutputCeArgs a) {
     // (the last iteration re-reads its own group)
     f32x4 fa[2], fb[NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) fa[i] = *(const f32x4 *)(xa[i]);
+    for (int i = 0; i < 2; ++i) fa[i] = *(const f32x4a4 *)(xa[i]);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) fb[j] = *(const f32x4 *)(wb[j]);
+    for (int j = 0; j < NT; ++j) fb[j] = *(const f32x4a4 *)(wb[j]);
     for (int kb = 0; kb < a.H; kb += 8) {
         const int kn = min(kb + 8, a.H - 8);
         f32x4 na[2], nb[NT];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) na[i] = *(const f32x4 *)(xa[i] + kn);
+        for (int i = 0; i < 2; ++i) na[i] = *(const f32x4a4 *)(xa[i] + kn);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) nb[j] = *(const f32x4 *)(wb[j] + kn);
+        for (int j = 0; j < NT; ++j) nb[j] = *(const f32x4a4 *)(wb[j] + kn);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -781,14 +784,13 @@ int pcm_output_ce(const float *x, int64_t ldx, const float *w,
                 (long long)ldx, hidden);
     hipStream_t st = (hipStream_t)stream;
     const long long rows = (long long)steps * batch;
-    const bool fused = vocab <= 128 && hidden % 8 == 0 && ldx % 4 == 0 &&
-                       ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0;
+    const bool fused = vocab <= 128 && hidden % 8 == 0;
     if (!fused) {
         // shapes outside the fused kernel: output layer, then the cross entropy
         PCM_REQUIRE(logits, PCM_EINVAL,
                     "output_ce: V=%d H=%d ldx=%lld needs a logits buffer (the "
-                    "fused kernel takes V <= 128, H %% 8 == 0, 16-byte aligned "
-                    "rows)", vocab, hidden, (long long)ldx);
+                    "fused kernel takes V <= 128 and H %% 8 == 0)", vocab, hidden,
+                    (long long)ldx);
         PCM_REQUIRE(rows <= 0x7fffffff, PCM_EINVAL, "output_ce: too many rows");
         int rc = pcm_linear_forward(x, ldx, w, bias, logits, vocab, (int32_t)rows,
                                     vocab, hidden, stream);

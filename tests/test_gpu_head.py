@@ -62,7 +62,14 @@ def test_output_ce_matches_reference_and_two_call_path(T, B, V, H, ragged,
     r_logits, r_loss, r_argmax, r_dlogits = _reference(
         x, w, b, targets, lengths, step_weight)
 
-    xd, wd, bd = x.to(dev), w.to(dev), b.to(dev)
+    # operands at odd 4-byte offsets of larger buffers, as parameters that live
+    # inside a flat optimizer buffer are
+    def odd(t, shift):
+        flat = torch.empty(t.numel() + shift, device=dev)
+        view = flat[shift:].view(t.shape)
+        view.copy_(t)
+        return view
+    xd, wd, bd = odd(x, 3), odd(w, 1), odd(b, 2)
     td = targets.to(dev)
     ld = lengths.to(dev, torch.int32) if ragged else None
     swd = step_weight.to(dev) if weighted else None
