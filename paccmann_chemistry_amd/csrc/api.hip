@@ -231,6 +231,8 @@ int pcm_sg_layout(const pcm_dims *d, int steps, int training, int dropout,
         o->off_xtop = take(off, (size_t)steps * o->B * o->Wp);
     }
     o->off_sync = take(off, pcm_persist_fwd_sync_words());
+    o->off_cspart =
+        take(off, o->use_stack ? (size_t)o->B * (o->Hn / 32) * 64 : 0);
     o->off_cpre = take(off, o->use_stack ? (size_t)steps * o->B * 64 : 0);
     o->off_tokg = take(off, (size_t)o->V * 3 * o->Hn);
     for (int l = 0; l < o->L; ++l) {
@@ -286,7 +288,12 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
                         float *const *bpack, const StepBufs &sb,
                         const int32_t *lengths, int t, float drop_p,
                         uint64_t seed, int32_t *status, hipStream_t st,
-                        int rows = -1, int b0 = 0) {
+                        int rows = -1, int b0 = 0, float *cs_part = nullptr,
+                        bool *have_part = nullptr) {
+    // cs_part / have_part: the top layer's forward cell may leave partial sums
+    // of the next step's stack controls (see CellFwdArgs); *have_part says, on
+    // entry, that the previous step left them for (at least) these rows, and on
+    // return whether this step did
     // The step over batch rows [b0, b0 + rows): rows = the length-sorted prefix
     // of the batch still running at this step (packed mode with a shrinking
     // active batch), or one chain's half of it; -1 = everything from b0 on.
@@ -306,6 +313,9 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         s.av = sb.av + oAV; s.xtop = sb.xtop + oX; s.lengths = len;
         s.B = Bt; s.H = lay.H; s.Hp = lay.Hp; s.D = lay.D; s.W = lay.W;
         s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
+        s.cs_part = (cs_part && have_part && *have_part)
+                        ? cs_part + (size_t)b0 * (lay.Hn / 32) * 64 : nullptr;
+        s.cs_parts = lay.Hn / 32;
         pcm_probe_begin(PCM_K_STACK_FWD);
         int rc = pcm_launch_stack_fwd(s, st);
         pcm_probe_end(PCM_K_STACK_FWD);
@@ -330,6 +340,20 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         c.t = t; c.next_layer = l + 1; c.b_off = b0;
         c.drop_p = drop_p; c.inv_keep = drop_p < 1.f ? 1.f / (1.f - drop_p) : 0.f;
         c.seed = seed;
+        c.cs_ctrl_w = c.cs_push_w = nullptr; c.cs_part = nullptr; c.cs_W = 0;
+        if (l == lay.L - 1 && have_part) {
+            *have_part = false;
+            if (cs_part && lay.use_stack && 3 + lay.W <= 64) {
+                c.cs_ctrl_w = w->ctrl_w; c.cs_push_w = w->push_w;
+                c.cs_part = cs_part + (size_t)b0 * (lay.Hn / 32) * 64;
+                c.cs_W = lay.W;
+                if (pcm_cell_fwd_writes_ctrl_partials(c)) {
+                    *have_part = true;
+                } else {
+                    c.cs_part = nullptr;
+                }
+            }
+        }
         pcm_probe_begin(PCM_K_CELL_FWD, l);
         int rc = pcm_launch_cell_fwd(c, st);
         pcm_probe_end(PCM_K_CELL_FWD, l);
@@ -635,6 +659,15 @@ int pcm_stackgru_forward(const pcm_dims *dims,
     if (!cs) split = 0;
     const int nch = split ? 2 : 1;
     if (split) stream_wait(cs, st, cs->stream);   // fork: state is initialised
+    // partial stack-control sums handed from a step's top cell to the next
+    // step's stack kernel (PCM_CTRL_PARTIALS=0: off)
+    static const bool ctrl_partials = [] {
+        const char *e = getenv("PCM_CTRL_PARTIALS");
+        return !e || atoi(e) != 0;
+    }();
+    float *cs_part = (ctrl_partials && lay.use_stack) ? sv + lay.off_cspart
+                                                      : nullptr;
+    bool have_part[2] = {false, false};
     for (int t = 0; t < steps && !persist; ++t) {
         StepBufs sb;
         memset(&sb, 0, sizeof(sb));
@@ -661,7 +694,8 @@ int pcm_stackgru_forward(const pcm_dims *dims,
             chain_rows(c, split, total, &b0, &n);
             rc = enqueue_step(lay, weights, sv + lay.off_tokg, wpack, bpack, sb,
                               lengths, t, dropout_p, seed, status,
-                              c == 0 ? st : cs->stream, n, b0);
+                              c == 0 ? st : cs->stream, n, b0, cs_part,
+                              &have_part[c]);
             if (rc) return rc;
         }
     }

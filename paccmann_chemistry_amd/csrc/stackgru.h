@@ -22,6 +22,8 @@ struct SGLayout {
     size_t off_xtop;   // T x B x Wp (a slot per step in both modes: the
                        // persistent kernel hands it over at fresh addresses)
     size_t off_sync;   // hand-off counters of the persistent kernel (words)
+    size_t off_cspart; // B x (Hn / 32) x 64: partial control / push sums that
+                       // the top layer's forward cell leaves for the next stack step
     size_t off_cpre;   // T x B x 64: stack control / push pre-activations the
                        // persistent kernel hands over (0 floats without a stack)
     size_t off_tokg;   // V x 3*Hn   token gate table (b_ih0 folded in)
@@ -79,8 +81,16 @@ struct CellFwdArgs {
                         // batch: the dropout hash is a function of the GLOBAL row)
     float drop_p, inv_keep;
     uint64_t seed;
+    // top layer with a stack: the block's share of the NEXT stack step's 3 + W
+    // control / push pre-activations, [row][column tile][64]
+    // (null: not wanted); cs_W = stack width
+    const float *cs_ctrl_w, *cs_push_w;
+    float *cs_part;
+    int cs_W;
 };
 int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream);
+// true when pcm_launch_cell_fwd will run `a` on the kernel that writes cs_part
+bool pcm_cell_fwd_writes_ctrl_partials(const CellFwdArgs &a);
 
 struct StackFwdArgs {
     const float *htop;   // [B, Hp] top-layer hidden before the step
@@ -91,6 +101,11 @@ struct StackFwdArgs {
     float *xtop;         // [B, Wp]
     const int32_t *lengths;
     int B, H, Hp, D, W, Wp, AVW, t;
+    // partial control / push sums left by the top layer's forward cell of the
+    // step before ([row][cs_parts][64], summed in order); null: the dot products
+    // are computed here
+    const float *cs_part;
+    int cs_parts;
 };
 int pcm_launch_stack_fwd(const StackFwdArgs &a, hipStream_t stream);
 // The stack kernels stage whole [D, W] stacks in LDS: PCM_OK if one batch row

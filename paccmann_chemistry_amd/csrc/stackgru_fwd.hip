@@ -82,11 +82,15 @@ __device__ __forceinline__ void raw_barrier() {
 
 // Gate math of one (batch row, hidden unit) from its four raw sums
 // s = {r, z, n (input side), n (hidden side)}: token-gate gather, biases,
-// sigma / tanh, (h - n) z + n, length freeze, gate save, dropout of the next
-// layer's input.
-__device__ __forceinline__ void cell_fwd_element(const CellFwdArgs &a, int b,
-                                                 int j, const float (&s)[4]) {
-    const int H = a.H, Hn = a.Hn;
+// sigma / tanh, (h - n) z + n, length freeze; then (cell_fwd_store) gate save,
+// new hidden state, dropout of the next layer's input.
+struct CellFwdOut {
+    float r, z, n, ghn, hn;
+};
+
+__device__ __forceinline__ CellFwdOut cell_fwd_math(const CellFwdArgs &a, int b,
+                                                    int j, const float (&s)[4]) {
+    const int Hn = a.Hn;
     float tr = 0.f, tz = 0.f, tn = 0.f;
     if (a.tokg) {
         long long tk = a.tok[b];
@@ -97,23 +101,35 @@ __device__ __forceinline__ void cell_fwd_element(const CellFwdArgs &a, int b,
         const float *tg = a.tokg + tk * (3LL * Hn);
         tr = tg[j]; tz = tg[Hn + j]; tn = tg[2 * Hn + j];
     }
-    const float r_ = pcm_sigmoid(s[0] + a.bpack[j] + tr);
-    const float z_ = pcm_sigmoid(s[1] + a.bpack[Hn + j] + tz);
-    const float ghn = s[3] + a.bpack[3 * Hn + j];
-    const float n_ = tanhf(s[2] + a.bpack[2 * Hn + j] + tn + r_ * ghn);
+    CellFwdOut o;
+    o.r = pcm_sigmoid(s[0] + a.bpack[j] + tr);
+    o.z = pcm_sigmoid(s[1] + a.bpack[Hn + j] + tz);
+    o.ghn = s[3] + a.bpack[3 * Hn + j];
+    o.n = tanhf(s[2] + a.bpack[2 * Hn + j] + tn + o.r * o.ghn);
     const float hp = a.hprev[(long long)b * a.Hp + j];
     // ATen GRU cell: (h - n) * z + n
-    float hn = __fadd_rn(__fmul_rn(hp - n_, z_), n_);
-    if (a.lengths && a.t >= a.lengths[b]) hn = hp;
-    a.hnew[(long long)b * a.Hp + j] = hn;
+    o.hn = __fadd_rn(__fmul_rn(hp - o.n, o.z), o.n);
+    if (a.lengths && a.t >= a.lengths[b]) o.hn = hp;
+    return o;
+}
+
+__device__ __forceinline__ void cell_fwd_store(const CellFwdArgs &a, int b, int j,
+                                               const CellFwdOut &o) {
+    const int H = a.H;
+    a.hnew[(long long)b * a.Hp + j] = o.hn;
     if (a.gates) {
         float *g = a.gates + (long long)b * 4 * H;
-        g[j] = r_; g[H + j] = z_; g[2 * H + j] = n_; g[3 * H + j] = ghn;
+        g[j] = o.r; g[H + j] = o.z; g[2 * H + j] = o.n; g[3 * H + j] = o.ghn;
     }
     if (a.xdrop)
         a.xdrop[(long long)b * a.Hp + j] =
-            hn * pcm_dropout_scale(a.seed, a.next_layer, a.t, b + a.b_off, j, a.drop_p,
-                                   a.inv_keep);
+            o.hn * pcm_dropout_scale(a.seed, a.next_layer, a.t, b + a.b_off, j,
+                                     a.drop_p, a.inv_keep);
+}
+
+__device__ __forceinline__ void cell_fwd_element(const CellFwdArgs &a, int b,
+                                                 int j, const float (&s)[4]) {
+    cell_fwd_store(a, b, j, cell_fwd_math(a, b, j, s));
 }
 
 // Cross-wave reduction of the four K-slice partials through LDS, then the GRU
@@ -124,7 +140,8 @@ __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
                                               const f32x16 &acc_ni,
                                               const f32x16 &acc_nh, int tid,
                                               int wave, int lrow, int lh,
-                                              int j0, int b0) {
+                                              int j0, int b0,
+                                              const f32x4 (&wf)[4]) {
     // cross-wave reduction of the 4 partial tiles through LDS
     __syncthreads();
     float *red = lds;  // [wave][tile][32][32]
@@ -142,6 +159,8 @@ __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
     __syncthreads();
 
     const int H = a.H;
+    CellFwdOut out[2];
+    bool live[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int e = tid + 512 * q;
@@ -155,9 +174,76 @@ __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
             for (int w = 0; w < 4; ++w) v += red[(w * 4 + tl) * 1024 + e];
             s[tl] = v;
         }
-        if (b >= a.B || j >= H) continue;
-        cell_fwd_element(a, b, j, s);
+        live[q] = b < a.B && j < H;
+        out[q].hn = 0.f;
+        if (live[q]) out[q] = cell_fwd_math(a, b, j, s);
     }
+    f32x16 part;
+    if (a.cs_part) {
+        // Top layer with a stack: this tile's share of the next stack step's
+        // 3 + W control / push pre-activations, [32 rows x 32 k] . [32 k x 64
+        // outputs] on waves 0 and 1 (one 32-output tile each; weight fragments
+        // in wf since kernel start), stored as partial number `column tile`,
+        // which the stack kernel sums in order -- it then no longer streams the
+        // whole [Wc ; Ws] per batch row.  Done
+        // BEFORE the epilogue's stores: raw barriers (LDS traffic only), so
+        // nothing here waits for a global store.
+        constexpr int HT = 36;     // row stride of the tile (conflict-free b128)
+        raw_barrier();             // every thread has read its sums from `red`
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 512 * q;
+            lds[(e >> 5) * HT + (e & 31)] = out[q].hn;
+        }
+        raw_barrier();
+        if (wave < 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 fa =
+                    *(const f32x4 *)(lds + lrow * HT + 4 * (2 * i + lh));
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    part = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], wf[i][e],
+                                                                part, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = tid + 512 * q;
+        if (live[q]) cell_fwd_store(a, b0 + (e >> 5), j0 + (e & 31), out[q]);
+    }
+    if (a.cs_part && wave < 2) {
+        const int parts = a.Hn / CN;
+        float *dst = a.cs_part + ((long long)b0 * parts + j0 / CN) * 64 +
+                     32 * wave + lrow;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (b0 + row < a.B) dst[(long long)row * parts * 64] = part[r];
+        }
+    }
+}
+
+// weight fragments of cell_fwd_tail's control partials: wave w < 2, lane
+// (lrow, lh) holds, for i = 0..3, the four k = j0 + 4 (2 i + lh) + 0..3 of output
+// 32 w + lrow (rows 0-2: controls, 3 .. 2 + W: push, beyond: zero)
+typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void cell_fwd_ctrl_frags(const CellFwdArgs &a,
+                                                    int wave, int lrow, int lh,
+                                                    int j0, f32x4 (&wf)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wf[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!a.cs_part || wave >= 2) return;
+    const int o = 32 * wave + lrow;
+    if (o >= 3 + a.cs_W) return;
+    const float *wrow = (o < 3 ? a.cs_ctrl_w + (long long)o * a.H
+                               : a.cs_push_w + (long long)(o - 3) * a.H) + j0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        wf[i] = *(const f32x4a4 *)(wrow + 4 * (2 * i + lh));
 }
 
 // Two 32 KiB stages, two raw barriers per chunk (A: chunk landed, B: fragments
@@ -187,6 +273,8 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
     for (int r = 0; r < 16; ++r) {
         acc_r[r] = 0.f; acc_z[r] = 0.f; acc_ni[r] = 0.f; acc_nh[r] = 0.f;
     }
+    f32x4 wf[4];
+    cell_fwd_ctrl_frags(a, wave, lrow, lh, j0, wf);
 
     if (wave >= 4) {
         // loaders: same lane -> (row, swizzled granule) map as above
@@ -279,7 +367,7 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
         for (int c = a.nx_chunks; c < nchunks; ++c) chunk(c, acc_nh);
     }
     cell_fwd_tail(a, lds, acc_r, acc_z, acc_ni, acc_nh, tid, wave, lrow, lh, j0,
-                  b0);
+                  b0, wf);
 }
 
 
@@ -664,15 +752,18 @@ __global__ __launch_bounds__(STHREADS, LEAN ? 4 : 2) void stack_step_fwd_kernel(
     const float inv_H = 1.0f / (float)H, inv_AVW = 1.0f / (float)a.AVW;
     const float inv_nq = 1.0f / (float)max(DW >> 2, 1);
     float *Srow = sm;                          // [SROWS][DWp]
-    float *hrow = Srow + SROWS * DWp;          // [SROWS][H]
-    float *cu = hrow + SROWS * H;              // [SROWS][AVW]
+    float *hrow = Srow + SROWS * DWp;          // [SROWS][max(H, 512)]
+    float *cu = hrow + SROWS * max(H, 512);    // [SROWS][AVW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * SROWS;
 
+    // partial sums left by the previous step's top cell stand in for the dot
+    // products (and for the hidden rows they would read)
+    const bool parts = a.cs_part != nullptr;
     // control / push weights of this wave's outputs go to registers FIRST so
     // their L2 round trip overlaps the staging loads below (H <= 512 path)
     constexpr int KS = 8;
-    const bool wregs = !LEAN && H <= 64 * KS && NO <= 8 * SOUT;
+    const bool wregs = !parts && !LEAN && H <= 64 * KS && NO <= 8 * SOUT;
     float wr[SOUT][KS];
     if (wregs) {
 #pragma unroll
@@ -688,7 +779,25 @@ __global__ __launch_bounds__(STHREADS, LEAN ? 4 : 2) void stack_step_fwd_kernel(
         }
     }
 
+    if (parts) {
+        // wave g sums partials [g * per, (g + 1) * per) of every output in
+        // order (loads coalesced over the outputs, in flight together with
+        // the stack loads below) and parks the group sum where the hidden rows
+        // would go: [row][group][output]
+        const int g = tid >> 6, o = tid & 63;
+        const int per = (a.cs_parts + 7) >> 3;
+        const int p0 = g * per, p1 = min(p0 + per, a.cs_parts);
+#pragma unroll
+        for (int r = 0; r < SROWS; ++r) {
+            const int b = min(b0 + r, a.B - 1);
+            const float *src = a.cs_part + (long long)b * a.cs_parts * 64 + o;
+            float v = 0.f;
+            for (int p = p0; p < p1; ++p) v += src[p * 64];
+            hrow[(r * 8 + g) * 64 + o] = v;
+        }
+    }
     // top-layer hidden rows -> LDS (needed first, by the dot products)
+    if (!parts)
     for (int idx = tid; idx < SROWS * H; idx += STHREADS) {
         const int r = pcm_fdiv(idx, inv_H), k = idx - r * H;
         const int b = b0 + r;
@@ -729,7 +838,17 @@ __global__ __launch_bounds__(STHREADS, LEAN ? 4 : 2) void stack_step_fwd_kernel(
     __syncthreads();
 
     // dot products: wave handles SOUT outputs per pass, lanes stride K
-    if (wregs) {
+    if (parts) {
+        // the eight group sums of every (row, output), in group order
+        for (int idx = tid; idx < SROWS * 64; idx += STHREADS) {
+            const int r = idx >> 6, o = idx & 63;
+            if (o >= NO) continue;
+            float v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) v += hrow[(r * 8 + g) * 64 + o];
+            cu[r * a.AVW + o] = v + (o < 3 ? a.ctrl_b[o] : a.push_b[o - 3]);
+        }
+    } else if (wregs) {
         float p[SOUT][SROWS];
 #pragma unroll
         for (int i = 0; i < SOUT; ++i)
@@ -1211,9 +1330,11 @@ int pcm_launch_gather_at_length(const float *buf, long long slot_floats,
     return 0;
 }
 
-int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
+// tile of the forward cell for this launch: 64 (64 x 64, thousands of rows),
+// 16 (32 rows x 16 units) or 32 (32 x 32)
+static int cell_fwd_tile(const CellFwdArgs &a) {
     static const int force = [] {
-        const char *e = getenv("PCM_FWD_TILE");   // 16 / 32: force a tile width
+        const char *e = getenv("PCM_FWD_TILE");   // 16 / 32 / 64: force a tile
         return e ? atoi(e) : 0;
     }();
     static const int cus = [] {
@@ -1224,6 +1345,8 @@ int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
         return n;
     }();
     const int nbt = (a.B + CM - 1) / CM;
+    // thousands of rows: 64 x 64 tiles (see the kernel)
+    if ((force ? force == 64 : a.B >= 2048) && (a.Hn % LN) == 0) return 64;
     // Narrow tiles when they balance better over the CUs: a wide block is two
     // units of work, a narrow one 1.06 (measured: 16.5 against 15.5 us at one
     // wide block per CU); compare the busiest CU's load.  Batch 512 -> wide
@@ -1231,18 +1354,26 @@ int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
     const int wide_tiles = (a.Hn / CN) * nbt;
     const float load_wide = 2.0f * ((wide_tiles + cus - 1) / cus);
     const float load_narrow = 1.06f * ((2 * wide_tiles + cus - 1) / cus);
-    // thousands of rows: 64 x 64 tiles (see the kernel)
-    const bool big = (force ? force == 64 : a.B >= 2048) && (a.Hn % LN) == 0;
-    if (big) {
+    const bool narrow = force ? force == 16 : load_narrow < load_wide;
+    return narrow ? 16 : 32;
+}
+
+bool pcm_cell_fwd_writes_ctrl_partials(const CellFwdArgs &a) {
+    // only the 32 x 32 kernel's tail computes them
+    return a.cs_part && a.H == a.Hn && (a.H % CN) == 0 && 3 + a.cs_W <= 64 &&
+           cell_fwd_tile(a) == 32;
+}
+
+int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
+    const int nbt = (a.B + CM - 1) / CM;
+    const int tile = cell_fwd_tile(a);
+    if (tile == 64) {
         dim3 grid(a.Hn / LN, (a.B + LM - 1) / LM);
         if (g_pcm_matmul_bf16)
             PCM_LAUNCH(gru_cell_fwd64_kernel<true>, grid, dim3(512), 0, stream, a);
         else
             PCM_LAUNCH(gru_cell_fwd64_kernel<false>, grid, dim3(512), 0, stream, a);
-        return 0;
-    }
-    const bool narrow = force ? force == 16 : load_narrow < load_wide;
-    if (narrow) {
+    } else if (tile == 16) {
         dim3 grid(a.Hn / NCN, nbt);
         if (g_pcm_matmul_bf16)
             PCM_LAUNCH(gru_cell_fwd16_kernel<true>, grid, dim3(512), 0, stream, a);
@@ -1262,14 +1393,14 @@ int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
 // top-layer hidden row, controls)
 static size_t stack_fwd_row_bytes(int D, int W, int H, int AVW) {
     const int DWp = (D * W + 3) & ~3;
-    return (size_t)(DWp + H + AVW) * sizeof(float);
+    return (size_t)(DWp + (H > 512 ? H : 512) + AVW) * sizeof(float);
 }
 
 int pcm_stack_fwd_check(int D, int W, int H, int AVW) {
     PCM_REQUIRE(stack_fwd_row_bytes(D, W, H, AVW) <= PCM_STACK_LDS_BYTES,
                 PCM_EINVAL,
                 "stack step: stack %dx%d + hidden %d exceed the %d KiB LDS row "
-                "cache (needs (D*W + H + W + 3) * 4 bytes per row)", D, W, H,
+                "cache (needs (D*W + max(H, 512) + W + 3) * 4 bytes per row)", D, W, H,
                 PCM_STACK_LDS_BYTES / 1024);
     return PCM_OK;
 }

@@ -48,25 +48,31 @@ def global_step_weights(lengths, steps, batch, device=None):
     per step; a single process gets 1 / local counts.
 
     lengths: per-row lengths of THIS rank's shard (None = padded mode, every
-    row runs ``steps`` steps)."""
+    row runs ``steps`` steps).  Padded mode: every rank must run the same
+    number of steps (pad the shards of one global batch to one length, as the
+    single-process ``pad_sequence`` does); the exchange is then ONE all-reduce
+    on the device with no host synchronisation.  Packed mode: shards may differ
+    in their longest sequence, so the longest T is exchanged first."""
+    size, _ = world()
+    on = 'cpu'
+    if size > 1 and dist.get_backend() == 'nccl':
+        on = device if device is not None else 'cuda'
     if lengths is None:
-        counts = torch.full((steps, ), int(batch), dtype=torch.int64)
+        counts = torch.full((steps, ), int(batch), dtype=torch.int64, device=on)
+        if size > 1:
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     else:
         lens = torch.as_tensor(lengths).to('cpu', torch.int64).view(1, -1)
         counts = (lens > torch.arange(steps).view(-1, 1)).sum(dim=1)
-    size, _ = world()
-    if size > 1:
-        # shards may differ in their longest sequence: count over the longest
-        # T of any rank (slot 0 carries T itself, reduced with MAX first)
-        on = 'cpu'
-        if dist.get_backend() == 'nccl':
-            on = device if device is not None else 'cuda'
-        longest = torch.tensor([steps], dtype=torch.int64, device=on)
-        dist.all_reduce(longest, op=dist.ReduceOp.MAX)
-        padded = torch.zeros(int(longest.item()), dtype=torch.int64, device=on)
-        padded[:steps] = counts.to(on)
-        dist.all_reduce(padded, op=dist.ReduceOp.SUM)
-        counts = padded[:steps]
+        if size > 1:
+            # count over the longest T of any rank (reduced with MAX first)
+            longest = torch.tensor([steps], dtype=torch.int64, device=on)
+            dist.all_reduce(longest, op=dist.ReduceOp.MAX)
+            padded = torch.zeros(int(longest.item()), dtype=torch.int64,
+                                 device=on)
+            padded[:steps] = counts.to(on)
+            dist.all_reduce(padded, op=dist.ReduceOp.SUM)
+            counts = padded[:steps]
     weights = torch.where(
         counts > 0, 1.0 / counts.clamp(min=1).to(torch.float32),
         torch.zeros(steps, dtype=torch.float32, device=counts.device)
