@@ -313,7 +313,11 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         s.av = sb.av + oAV; s.xtop = sb.xtop + oX; s.lengths = len;
         s.B = Bt; s.H = lay.H; s.Hp = lay.Hp; s.D = lay.D; s.W = lay.W;
         s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
-        s.cs_part = (cs_part && have_part && *have_part)
+        static const bool consume = [] {
+            const char *e = getenv("PCM_CTRL_PARTIALS");
+            return !e || atoi(e) != 2;
+        }();
+        s.cs_part = (cs_part && have_part && *have_part && consume)
                         ? cs_part + (size_t)b0 * (lay.Hn / 32) * 64 : nullptr;
         s.cs_parts = lay.Hn / 32;
         pcm_probe_begin(PCM_K_STACK_FWD);
@@ -661,9 +665,9 @@ int pcm_stackgru_forward(const pcm_dims *dims,
     if (split) stream_wait(cs, st, cs->stream);   // fork: state is initialised
     // partial stack-control sums handed from a step's top cell to the next
     // step's stack kernel (PCM_CTRL_PARTIALS=0: off)
-    static const bool ctrl_partials = [] {
+    static const int ctrl_partials = [] {
         const char *e = getenv("PCM_CTRL_PARTIALS");
-        return !e || atoi(e) != 0;
+        return e ? atoi(e) : 1;   // 2 (diagnostics): written, not consumed
     }();
     float *cs_part = (ctrl_partials && lay.use_stack) ? sv + lay.off_cspart
                                                       : nullptr;

@@ -119,7 +119,11 @@ __device__ __forceinline__ void cell_fwd_store(const CellFwdArgs &a, int b, int 
     a.hnew[(long long)b * a.Hp + j] = o.hn;
     if (a.gates) {
         float *g = a.gates + (long long)b * 4 * H;
-        g[j] = o.r; g[H + j] = o.z; g[2 * H + j] = o.n; g[3 * H + j] = o.ghn;
+        // read again only by the reverse pass: streaming stores
+        __builtin_nontemporal_store(o.r, g + j);
+        __builtin_nontemporal_store(o.z, g + H + j);
+        __builtin_nontemporal_store(o.n, g + 2 * H + j);
+        __builtin_nontemporal_store(o.ghn, g + 3 * H + j);
     }
     if (a.xdrop)
         a.xdrop[(long long)b * a.Hp + j] =
@@ -141,7 +145,7 @@ __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
                                               const f32x16 &acc_nh, int tid,
                                               int wave, int lrow, int lh,
                                               int j0, int b0,
-                                              const f32x4 (&wf)[4]) {
+                                              const f32x4 (&wf)[2]) {
     // cross-wave reduction of the 4 partial tiles through LDS
     __syncthreads();
     float *red = lds;  // [wave][tile][32][32]
@@ -178,16 +182,18 @@ __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
         out[q].hn = 0.f;
         if (live[q]) out[q] = cell_fwd_math(a, b, j, s);
     }
-    f32x16 part;
+    f32x4 part = {0.f, 0.f, 0.f, 0.f};
     if (a.cs_part) {
         // Top layer with a stack: this tile's share of the next stack step's
         // 3 + W control / push pre-activations, [32 rows x 32 k] . [32 k x 64
-        // outputs] on waves 0 and 1 (one 32-output tile each; weight fragments
-        // in wf since kernel start), stored as partial number `column tile`,
-        // which the stack kernel sums in order -- it then no longer streams the
-        // whole [Wc ; Ws] per batch row.  Done
-        // BEFORE the epilogue's stores: raw barriers (LDS traffic only), so
-        // nothing here waits for a global store.
+        // outputs] as eight 16 x 16 tiles, one per wave (loaders included: row
+        // half w & 1, output tile w >> 1; 16x16x4 MFMAs, weight fragments in wf
+        // since kernel start), stored as partial number `column tile`, which
+        // the stack kernel sums in order -- it then no longer streams the whole
+        // [Wc ; Ws] per batch row.  Done BEFORE the epilogue's stores, between
+        // raw barriers (LDS traffic only), so nothing here waits for a global
+        // store; four stores per lane (two waves with 32 x 32 tiles and sixteen
+        // stores per lane cost the launch 1.2 us, all of it in those stores).
         constexpr int HT = 36;     // row stride of the tile (conflict-free b128)
         raw_barrier();             // every thread has read its sums from `red`
 #pragma unroll
@@ -196,54 +202,56 @@ __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
             lds[(e >> 5) * HT + (e & 31)] = out[q].hn;
         }
         raw_barrier();
-        if (wave < 2) {
+#ifndef PCM_DBG_NO_PMFMA
+        const int r16 = tid & 15, g = (tid >> 4) & 3;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) part[r] = 0.f;
+        for (int jj = 0; jj < 2; ++jj) {
+            const f32x4 fa = *(const f32x4 *)(lds + (16 * (wave & 1) + r16) * HT +
+                                              16 * jj + 4 * g);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 fa =
-                    *(const f32x4 *)(lds + lrow * HT + 4 * (2 * i + lh));
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    part = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], wf[i][e],
-                                                                part, 0, 0, 0);
-            }
+            for (int e = 0; e < 4; ++e)
+                part = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], wf[jj][e], part,
+                                                            0, 0, 0);
         }
+#endif
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int e = tid + 512 * q;
         if (live[q]) cell_fwd_store(a, b0 + (e >> 5), j0 + (e & 31), out[q]);
     }
-    if (a.cs_part && wave < 2) {
+#if !defined(PCM_DBG_NO_PMFMA) && !defined(PCM_DBG_NO_PSTORE)
+    if (a.cs_part) {
+        // D[i][j]: lane (r16, g) holds rows i = 4 g + e of the half, column r16
+        const int r16 = tid & 15, g = (tid >> 4) & 3;
         const int parts = a.Hn / CN;
         float *dst = a.cs_part + ((long long)b0 * parts + j0 / CN) * 64 +
-                     32 * wave + lrow;
+                     16 * (wave >> 1) + r16;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (b0 + row < a.B) dst[(long long)row * parts * 64] = part[r];
+        for (int e = 0; e < 4; ++e) {
+            const int row = 16 * (wave & 1) + 4 * g + e;
+            if (b0 + row < a.B) dst[(long long)row * parts * 64] = part[e];
         }
     }
+#endif
 }
 
-// weight fragments of cell_fwd_tail's control partials: wave w < 2, lane
-// (lrow, lh) holds, for i = 0..3, the four k = j0 + 4 (2 i + lh) + 0..3 of output
-// 32 w + lrow (rows 0-2: controls, 3 .. 2 + W: push, beyond: zero)
+// weight fragments of cell_fwd_tail's control partials: lane (r16, g) of wave w
+// holds, for jj = 0, 1, the four k = j0 + 16 jj + 4 g + 0..3 of output
+// 16 (w >> 1) + r16 (rows 0-2: controls, 3 .. 2 + W: push, beyond: zero)
 typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ void cell_fwd_ctrl_frags(const CellFwdArgs &a,
-                                                    int wave, int lrow, int lh,
-                                                    int j0, f32x4 (&wf)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wf[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!a.cs_part || wave >= 2) return;
-    const int o = 32 * wave + lrow;
+                                                    int wave, int lane, int j0,
+                                                    f32x4 (&wf)[2]) {
+    wf[0] = wf[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!a.cs_part) return;
+    const int o = 16 * (wave >> 1) + (lane & 15), g = lane >> 4;
     if (o >= 3 + a.cs_W) return;
     const float *wrow = (o < 3 ? a.cs_ctrl_w + (long long)o * a.H
                                : a.cs_push_w + (long long)(o - 3) * a.H) + j0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        wf[i] = *(const f32x4a4 *)(wrow + 4 * (2 * i + lh));
+    for (int jj = 0; jj < 2; ++jj)
+        wf[jj] = *(const f32x4a4 *)(wrow + 16 * jj + 4 * g);
 }
 
 // Two 32 KiB stages, two raw barriers per chunk (A: chunk landed, B: fragments
@@ -273,8 +281,8 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
     for (int r = 0; r < 16; ++r) {
         acc_r[r] = 0.f; acc_z[r] = 0.f; acc_ni[r] = 0.f; acc_nh[r] = 0.f;
     }
-    f32x4 wf[4];
-    cell_fwd_ctrl_frags(a, wave, lrow, lh, j0, wf);
+    f32x4 wf[2];
+    cell_fwd_ctrl_frags(a, wave, lane, j0, wf);
 
     if (wave >= 4) {
         // loaders: same lane -> (row, swizzled granule) map as above
