@@ -94,10 +94,12 @@ def probe_families(p, batch, seq_len):
     stack_bwd = (3 * depth * width * 4 + 9 * hid * 4) * batch
     # weight gradients of one StackGRU, the square-ish products that go
     # through the wide K-major GEMM launches: dW_hh of every layer and dW_ih of
-    # layers >= 1 (the skinny stack-top / control / token products are separate,
-    # narrow launches and are not priced here)
-    dw = (2 * 3 * hid * hid + (layers - 1) * 2 * 3 * hid * 2 * hid) \
-        * batch * seq_len
+    # layers >= 1 (the skinny control / push product is a separate, narrow
+    # launch and is not priced here)
+    # ... plus the joint [stack top | one-hot token] product of layer 0 (128
+    # columns, of which width + vocabulary carry gradient)
+    dw = (2 * 3 * hid * hid + (layers - 1) * 2 * 3 * hid * 2 * hid
+          + 2 * 3 * hid * 128) * batch * seq_len
     fams = [
         (11, 'gru_cell_fwd_kernel (layer 0)', 'mfma', l0),
         (2, 'stack_step_fwd_kernel', 'hbm', stack_fwd),

@@ -255,10 +255,11 @@ int pcm_sg_scratch(const SGLayout &lay, SGScratch *o) {
     o->off_dtop = take(off, (size_t)lay.B * (lay.use_stack
                                 ? (size_t)lay.Wp * std::max(1, lay.H / lay.Wp)
                                 : 1));
-    o->off_onehot = take(off, (size_t)lay.T * lay.B * lay.V);
+    o->off_onehot =
+        take(off, (size_t)lay.T * lay.B * (lay.V > 128 ? lay.V : 128));
     o->off_dtokg = take(off, (size_t)lay.V * 3 * lay.H);
     o->off_tmp = take(off, (size_t)lay.B * lay.Hp);
-    o->off_dwx = take(off, (size_t)3 * lay.H * (lay.Wp > 0 ? lay.Wp : 4));
+    o->off_dwx = take(off, (size_t)3 * lay.H * (lay.Wp > 128 ? lay.Wp : 128));
     o->off_dcw = take(off, (size_t)(lay.AVW > 0 ? lay.AVW : 4) * (lay.H + 1));
     for (int l = 0; l < lay.L; ++l)
         o->off_wpackT[l] =
@@ -863,10 +864,45 @@ int pcm_stackgru_backward(const pcm_dims *dims,
         // sums of the A operand where the K-major kernel takes the batch.
         bool bih_done[PCM_MAX_LAYERS] = {}, bhh_done[PCM_MAX_LAYERS] = {};
         bool cb_done = false;
+        const float *G0 = sv + lay.off_gates[0] + r0 * 4 * H;
+        const bool pad_ok = (R % 16) == 0 && (H % 4) == 0;
+        float *dwx = scf + sc.off_dwx, *dcw = scf + sc.off_dcw;
+        float *onehot = scf + sc.off_onehot;
+        float *dtokg = scf + sc.off_dtokg;
+        const bool tok_path = grads->w_ih[0] || grads->emb;
+        // One call over all steps (the default): the stack-top columns of W_ih0
+        // and the token table share their left operand (layer 0's gate
+        // gradients), so they are ONE wide product against [stack top | one-hot
+        // token] (128 columns) in the wide launch -- the gate gradients are read
+        // once and no tile is half empty: dwx[3H][128] = [dW_ih0[:, E:] | dtokg^T]
+        const bool merged = pad_ok && first && last && lay.use_stack &&
+                            grads->w_ih[0] && lay.Wp <= 64 && lay.V <= 64;
         {
-            GemmProb big[3 * PCM_MAX_LAYERS];
-            int tag[3 * PCM_MAX_LAYERS];  // layer * 2 + (0: b_hh, 1: b_ih)
+            GemmProb big[3 * PCM_MAX_LAYERS + 1];
+            int tag[3 * PCM_MAX_LAYERS + 1];  // layer * 2 + (0: b_hh, 1: b_ih)
             int nbig = 0;
+            if (merged) {
+                pcm_launch_xcat(sv + lay.off_xtop + r0 * lay.Wp, lay.Wp,
+                                tokens + r0, (long long)R, lay.V, onehot, gst);
+                GemmProb p = pcm_gemm_prob(G0, 1, 4LL * H, onehot, 128, 1, dwx,
+                                           128, 3 * H, 128, R);
+                if (grads->b_ih[0]) {
+                    p.colsum1 = grads->b_ih[0];
+                    p.cs_accumulate = cacc;
+                }
+                // a launch of its own: 12 tiles x 64 splits = one full round of
+                // resident blocks (inside the wide batch its 12 tiles left the
+                // last round of 156 x 16 blocks a quarter full: +250 us)
+                gb.count = 0;
+                gb.p[gb.count++] = p;
+                if (pcm_gemm_takes_colsum(gb, true)) {
+                    if (p.colsum1) bih_done[0] = true;
+                } else {
+                    gb.p[0].colsum1 = nullptr;
+                }
+                r = flush();
+                if (r) return r;
+            }
             for (int l = 0; l < L; ++l) {
                 const float *G = sv + lay.off_gates[l] + r0 * 4 * H;
                 const float *hprev = sv + lay.off_hs[l] + r0 * Hp;
@@ -920,15 +956,9 @@ int pcm_stackgru_backward(const pcm_dims *dims,
         // is stored Wp wide with zero padding, the controls AVW wide) so the
         // K-major kernel takes them; the valid block is then added to the
         // gradient.  Otherwise the strided generic kernel computes them in place.
-        const float *G0 = sv + lay.off_gates[0] + r0 * 4 * H;
-        const bool pad_ok = (R % 16) == 0 && (H % 4) == 0;
-        float *dwx = scf + sc.off_dwx, *dcw = scf + sc.off_dcw;
-        float *onehot = scf + sc.off_onehot;
-        float *dtokg = scf + sc.off_dtokg;
-        const bool tok_path = grads->w_ih[0] || grads->emb;
-        if (tok_path)
+        if (tok_path && !merged)
             pcm_launch_onehot(tokens + r0, (long long)R, lay.V, onehot, gst);
-        if (grads->w_ih[0] && lay.use_stack) {
+        if (grads->w_ih[0] && lay.use_stack && !merged) {
             GemmProb p = pad_ok
                 ? pcm_gemm_prob(G0, 1, 4LL * H, sv + lay.off_xtop + r0 * lay.Wp,
                                 lay.Wp, 1, dwx, lay.Wp, 3 * H, lay.Wp, R)
@@ -966,7 +996,7 @@ int pcm_stackgru_backward(const pcm_dims *dims,
             }
         }
         // token path: dtokg (+)= onehot^T . dGi0; at the end dW_ih0[:, :E], dEmb
-        if (tok_path) {
+        if (tok_path && !merged) {
             GemmProb p = pcm_gemm_prob(onehot, 1, lay.V, G0, 4LL * H, 1, dtokg,
                                        3LL * H, lay.V, 3 * H, R);
             p.accumulate = first ? 0 : 1;
@@ -995,8 +1025,9 @@ int pcm_stackgru_backward(const pcm_dims *dims,
         }
         if (pad_ok && lay.use_stack) {
             if (grads->w_ih[0])
-                pcm_launch_add_block(dwx, lay.Wp, grads->w_ih[0] + lay.E, ld0,
-                                     3 * H, lay.W, cacc, gst);
+                pcm_launch_add_block(dwx, merged ? 128 : lay.Wp,
+                                     grads->w_ih[0] + lay.E, ld0, 3 * H, lay.W,
+                                     cacc, gst);
             if (grads->ctrl_w)
                 pcm_launch_add_block(dcw, H, grads->ctrl_w, H, 3, H, cacc, gst);
             if (grads->push_w)
@@ -1006,15 +1037,20 @@ int pcm_stackgru_backward(const pcm_dims *dims,
         if (tok_path && last) {
             GemmBatch g2;
             g2.count = 0;
+            // dtokg[v][c]: its own [V][3H] buffer, or (merged) column 64 + v of
+            // row c of dwx
+            const float *tg = merged ? dwx + 64 : dtokg;
+            const long long tg_v = merged ? 1 : 3LL * H;    // stride over v
+            const long long tg_c = merged ? 128 : 1;        // stride over c
             if (grads->w_ih[0]) {
-                GemmProb p = pcm_gemm_prob(dtokg, 1, 3LL * H, weights->emb,
+                GemmProb p = pcm_gemm_prob(tg, tg_c, tg_v, weights->emb,
                                            lay.E, 1, grads->w_ih[0], ld0,
                                            3 * H, lay.E, lay.V);
                 p.accumulate = acc;
                 g2.p[g2.count++] = p;
             }
             if (grads->emb) {
-                GemmProb p = pcm_gemm_prob(dtokg, 3LL * H, 1,
+                GemmProb p = pcm_gemm_prob(tg, tg_v, tg_c,
                                            weights->w_ih[0], ld0, 1,
                                            grads->emb, lay.E, lay.V, lay.E,
                                            3 * H);

@@ -230,6 +230,8 @@ int pcm_launch_dropout_mask_mul(float *x, long long ldx, int B, int H,
                                 uint64_t seed, int layer, int t, float p,
                                 hipStream_t stream);
 // out[row][v] = (tokens[row] == v)
+int pcm_launch_xcat(const float *xtop, int Wp, const int64_t *tokens,
+                    long long rows, int V, float *out, hipStream_t stream);
 int pcm_launch_onehot(const int64_t *tokens, long long rows, int V, float *out,
                       hipStream_t stream);
 int pcm_launch_fill(float *dst, float value, long long n, hipStream_t stream);

@@ -689,6 +689,34 @@ __global__ __launch_bounds__(256) void onehot_kernel(const int64_t *tokens,
     }
 }
 
+// [rows][128]: columns 0-63 the stack top fed to layer 0 (Wp <= 64 wide, zero
+// beyond), columns 64-127 the one-hot token -- the joint right-hand operand of
+// the stack-top and token-table weight gradients
+__global__ __launch_bounds__(256) void xcat_kernel(const float *xtop, int Wp,
+                                                   const int64_t *tokens,
+                                                   long long rows, int V,
+                                                   float *out) {
+    const long long total = rows * 32;   // float4 groups
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * 256) {
+        const long long r = idx >> 5;
+        const int c = (int)(idx & 31) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < 64) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (c + i < Wp) v[i] = xtop[r * Wp + c + i];
+        } else {
+            long long tk = tokens[r];
+            tk = tk < 0 ? 0 : (tk >= V ? V - 1 : tk);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                v[i] = (tk == c - 64 + i) ? 1.f : 0.f;
+        }
+        *(f32x4 *)(out + r * 128 + c) = v;
+    }
+}
+
 int grid_for(long long n) {
     long long g = (n + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -817,6 +845,13 @@ int pcm_launch_dropout_add(float *dst, long long ldd, const float *src,
     hipLaunchKernelGGL(dropout_add_kernel, dim3(grid_for((long long)B * H)),
                        dim3(256), 0, stream, dst, ldd, src, lds_, B, H, seed,
                        layer, t, p, 1.0f / (1.0f - p));
+    return 0;
+}
+
+int pcm_launch_xcat(const float *xtop, int Wp, const int64_t *tokens,
+                    long long rows, int V, float *out, hipStream_t stream) {
+    hipLaunchKernelGGL(xcat_kernel, dim3(grid_for(rows * 32)), dim3(256), 0,
+                       stream, xtop, Wp, tokens, rows, V, out);
     return 0;
 }
 
