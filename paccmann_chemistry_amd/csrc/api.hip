@@ -305,7 +305,28 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
     const size_t oS = (size_t)b0 * lay.DW, oAV = (size_t)b0 * lay.AVW;
     const size_t oX = (size_t)b0 * lay.Wp;
     const int32_t *len = lengths ? lengths + b0 : nullptr;
-    if (lay.use_stack) {
+    // Stack step fused into the cells (opt-in, PCM_FUSE_STACK=1): with the
+    // previous step's control partials at hand, layer 0's cell derives controls,
+    // push value and the new stack top itself and the top layer's launch carries
+    // the stack update as extra blocks -- two launches per step instead of
+    // three.  Measured 26.03 against 26.25 ms per step: the prologue (every
+    // block of a row tile pulls the same 16 partials per row: 2.5 us) and the
+    // update blocks (+1.9 us on the top cell) cost what the stack launch costs,
+    // so the default keeps the three-launch step and its per-kernel pricing.
+    static const bool fuse_enabled = [] {
+        const char *e = getenv("PCM_FUSE_STACK");
+        return e && atoi(e) == 1;
+    }();
+    bool fuse = false;
+    if (fuse_enabled && lay.use_stack && lay.L >= 2 && cs_part && have_part &&
+        *have_part && lay.Kxp[0] == 64 && lay.Wp == 64 && lay.AVW <= 64 &&
+        3 + lay.W <= 64 && lay.H == lay.Hn) {
+        CellFwdArgs probe;
+        memset(&probe, 0, sizeof(probe));
+        probe.B = Bt; probe.Hn = lay.Hn;
+        fuse = pcm_cell_fwd_tile(probe) == 32;
+    }
+    if (lay.use_stack && !fuse) {
         StackFwdArgs s;
         s.htop = sb.h_prev[lay.L - 1] + oH;
         s.S_prev = sb.S_prev + oS; s.S_new = sb.S_new + oS;
@@ -314,11 +335,7 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         s.av = sb.av + oAV; s.xtop = sb.xtop + oX; s.lengths = len;
         s.B = Bt; s.H = lay.H; s.Hp = lay.Hp; s.D = lay.D; s.W = lay.W;
         s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
-        static const bool consume = [] {
-            const char *e = getenv("PCM_CTRL_PARTIALS");
-            return !e || atoi(e) != 2;
-        }();
-        s.cs_part = (cs_part && have_part && *have_part && consume)
+        s.cs_part = (cs_part && have_part && *have_part)
                         ? cs_part + (size_t)b0 * (lay.Hn / 32) * 64 : nullptr;
         s.cs_parts = lay.Hn / 32;
         pcm_probe_begin(PCM_K_STACK_FWD);
@@ -346,6 +363,21 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         c.drop_p = drop_p; c.inv_keep = drop_p < 1.f ? 1.f / (1.f - drop_p) : 0.f;
         c.seed = seed;
         c.cs_ctrl_w = c.cs_push_w = nullptr; c.cs_part = nullptr; c.cs_W = 0;
+        c.xt_part = nullptr; c.su_S = nullptr;
+        if (fuse && l == 0) {
+            c.xt_part = cs_part + (size_t)b0 * (lay.Hn / 32) * 64;
+            c.xt_parts = lay.Hn / 32;
+            c.xt_ctrl_b = w->ctrl_b; c.xt_push_b = w->push_b;
+            c.xt_S = sb.S_prev + oS;
+            c.xt_av = sb.av + oAV; c.xt_xtop = sb.xtop + oX;
+            c.xt_W = lay.W; c.xt_D = lay.D; c.xt_AVW = lay.AVW;
+        }
+        if (fuse && l == lay.L - 1) {
+            c.su_S = sb.S_prev + oS; c.su_Snew = sb.S_new + oS;
+            c.su_av = sb.av + oAV;
+            c.su_nbt = (Bt + 31) / 32; c.su_rows = 2;
+            c.su_D = lay.D; c.su_W = lay.W; c.su_AVW = lay.AVW;
+        }
         if (l == lay.L - 1 && have_part) {
             *have_part = false;
             if (cs_part && lay.use_stack && 3 + lay.W <= 64) {
@@ -666,9 +698,9 @@ int pcm_stackgru_forward(const pcm_dims *dims,
     if (split) stream_wait(cs, st, cs->stream);   // fork: state is initialised
     // partial stack-control sums handed from a step's top cell to the next
     // step's stack kernel (PCM_CTRL_PARTIALS=0: off)
-    static const int ctrl_partials = [] {
+    static const bool ctrl_partials = [] {
         const char *e = getenv("PCM_CTRL_PARTIALS");
-        return e ? atoi(e) : 1;   // 2 (diagnostics): written, not consumed
+        return !e || atoi(e) != 0;
     }();
     float *cs_part = (ctrl_partials && lay.use_stack) ? sv + lay.off_cspart
                                                       : nullptr;

@@ -87,8 +87,27 @@ struct CellFwdArgs {
     const float *cs_ctrl_w, *cs_push_w;
     float *cs_part;
     int cs_W;
+    // Layer 0 with the stack step fused in (xt_part != null; the partials are
+    // the previous step's cs_part): every block derives the controls, the push
+    // value and the NEW stack top of its 32 rows itself and feeds it to the
+    // input-side chunk; column tile 0 records controls / push value (xt_av) and
+    // the stack top (xt_xtop) for the reverse pass and for the update below.
+    const float *xt_part, *xt_ctrl_b, *xt_push_b;
+    const float *xt_S;     // [B][DW] stack before the step
+    float *xt_av, *xt_xtop;
+    int xt_parts, xt_W, xt_D, xt_AVW;
+    // Top layer carrying the deferred stack update of the same step as extra
+    // blocks (blockIdx.y >= su_nbt, su_rows rows each; su_S == null: none):
+    // S_new = update(S, controls, push value) -- off the critical path, the
+    // next step's layer 0 only needs it after this launch has ended.
+    const float *su_S, *su_av;
+    float *su_Snew;
+    int su_nbt, su_rows, su_D, su_W, su_AVW;
 };
 int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream);
+// tile the forward cell launcher picks for `a` (16, 32 or 64); the fused stack
+// step (xt_*, su_*) lives in the 32 x 32 kernel only
+int pcm_cell_fwd_tile(const CellFwdArgs &a);
 // true when pcm_launch_cell_fwd will run `a` on the kernel that writes cs_part
 bool pcm_cell_fwd_writes_ctrl_partials(const CellFwdArgs &a);
 

@@ -202,7 +202,6 @@ __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
             lds[(e >> 5) * HT + (e & 31)] = out[q].hn;
         }
         raw_barrier();
-#ifndef PCM_DBG_NO_PMFMA
         const int r16 = tid & 15, g = (tid >> 4) & 3;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
@@ -213,14 +212,12 @@ __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
                 part = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], wf[jj][e], part,
                                                             0, 0, 0);
         }
-#endif
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int e = tid + 512 * q;
         if (live[q]) cell_fwd_store(a, b0 + (e >> 5), j0 + (e & 31), out[q]);
     }
-#if !defined(PCM_DBG_NO_PMFMA) && !defined(PCM_DBG_NO_PSTORE)
     if (a.cs_part) {
         // D[i][j]: lane (r16, g) holds rows i = 4 g + e of the half, column r16
         const int r16 = tid & 15, g = (tid >> 4) & 3;
@@ -233,7 +230,6 @@ __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
             if (b0 + row < a.B) dst[(long long)row * parts * 64] = part[e];
         }
     }
-#endif
 }
 
 // weight fragments of cell_fwd_tail's control partials: lane (r16, g) of wave w
@@ -254,6 +250,147 @@ __device__ __forceinline__ void cell_fwd_ctrl_frags(const CellFwdArgs &a,
         wf[jj] = *(const f32x4a4 *)(wrow + 16 * jj + 4 * g);
 }
 
+typedef float f32x4u4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// Stack step fused into layer 0's cell (CellFwdArgs::xt_*): the block's 32 rows'
+// control / push pre-activations are the bias plus the partial sums the top
+// cell of the step before left (one [row][64] per column tile, summed in
+// order), then softmax / tanh and the NEW stack top
+//   top = no_op * S[0] + push * v + pop * S[1]      (stack_rnn.py:229-231 order)
+// which goes straight into the activation rows of stage 0 (the input-side chunk,
+// granule-swizzled like a DMA'd chunk).  16 threads per row, four outputs each.
+// Column tile 0 records controls + push value and the stack top.  Every wave
+// calls this once, before its loop (two raw barriers inside).
+__device__ __forceinline__ void cell_fwd_xtop_prologue(const CellFwdArgs &a,
+                                                       float *lds, int tid,
+                                                       int b0, int ct) {
+    // (all eight waves, one row per 16 threads: the consumer waves alone, two
+    // rows per thread, measured 2.4 us slower per launch)
+    const int r = tid >> 4, og = tid & 15;
+    const int W = a.xt_W, D = a.xt_D;
+    const bool valid = b0 + r < a.B;
+    const int b = min(b0 + r, a.B - 1);
+    // the two stack rows the top depends on, this thread's four columns
+    const float *S0 = a.xt_S + (long long)b * D * W;
+    float s0[4], s1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int w = 4 * og + i;
+        s0[i] = w < W ? S0[w] : 0.f;
+        s1[i] = (w < W && D > 1) ? S0[W + w] : 0.f;
+    }
+    // (all partial loads in flight at once: a rolled loop would pay one L2
+    // round trip per partial -- measured 7 us for 16 of them)
+    const float *pp = a.xt_part + (long long)b * a.xt_parts * 64 + 4 * og;
+    f32x4 pv[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+        pv[p] = p < a.xt_parts ? *(const f32x4 *)(pp + p * 64)
+                               : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 16; ++p) sum += pv[p];
+    for (int p = 16; p < a.xt_parts; ++p) sum += *(const f32x4 *)(pp + p * 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int o = 4 * og + i;
+        sum[i] += o < 3 ? a.xt_ctrl_b[o] : (o < 3 + W ? a.xt_push_b[o - 3] : 0.f);
+    }
+    float *pre = lds;   // [32][64]: stage 0's activation rows, plain layout
+    *(f32x4 *)(pre + r * 64 + 4 * og) = sum;
+    raw_barrier();
+    const float *c = pre + r * 64;
+    const float m = fmaxf(c[0], fmaxf(c[1], c[2]));
+    const float e0 = expf(c[0] - m), e1 = expf(c[1] - m), e2 = expf(c[2] - m);
+    const float es = e0 + e1 + e2;
+    const float a_push = e0 / es, a_pop = e1 / es, a_noop = e2 / es;
+    const bool frozen = valid && a.lengths && a.t >= a.lengths[b];
+    f32x4 top, rec;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int w = 4 * og + i, o = w;
+        const float v = w < W ? tanhf(c[3 + w]) : 0.f;
+        float nv = __fadd_rn(__fadd_rn(__fmul_rn(a_noop, s0[i]),
+                                       __fmul_rn(a_push, v)),
+                             __fmul_rn(a_pop, s1[i]));
+        if (frozen) nv = s0[i];
+        top[i] = w < W ? nv : 0.f;
+        // record o (column tile 0 only): the three controls, then tanh of the
+        // push pre-activations
+        rec[i] = 0.f;
+        if (ct == 0)
+            rec[i] = o == 0 ? a_push
+                            : (o == 1 ? a_pop
+                                      : (o == 2 ? a_noop
+                                                : (o < 3 + W ? tanhf(c[o])
+                                                             : 0.f)));
+    }
+    raw_barrier();   // every thread has read the pre-activations
+    *(f32x4 *)(lds + r * 64 + ((og ^ (r & 15)) << 2)) = top;
+    if (ct == 0 && valid) {
+        *(f32x4 *)(a.xt_xtop + (long long)b * 64 + 4 * og) = top;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * og + i < a.xt_AVW)
+                a.xt_av[(long long)b * a.xt_AVW + 4 * og + i] = rec[i];
+    }
+}
+
+// Deferred stack update (CellFwdArgs::su_*): rows [row0, row0 + su_rows) of
+//   S_new = no_op * S + push * [v ; S[:-1]] + pop * [S[1:] ; 0]
+// with the controls / push value the fused layer-0 cell recorded; the arithmetic
+// (and its order) is stack_step_fwd_kernel's.
+__device__ __forceinline__ void cell_fwd_stack_update(const CellFwdArgs &a,
+                                                      int row0, int tid) {
+    const int W = a.su_W, D = a.su_D, DW = D * W;
+    for (int rr = 0; rr < a.su_rows; ++rr) {
+        const int b = row0 + rr;
+        if (b >= a.B) return;
+        const float *Sp = a.su_S + (long long)b * DW;
+        float *Sn = a.su_Snew + (long long)b * DW;
+        const float *c = a.su_av + (long long)b * a.su_AVW;
+        const bool frozen = a.lengths && a.t >= a.lengths[b];
+        const float c0 = c[0], c1 = c[1], c2 = c[2];
+        if ((DW & 3) == 0) {
+            for (int q = tid; q < (DW >> 2); q += 512) {
+                const int e0 = q * 4;
+                const f32x4 sv = *(const f32x4 *)(Sp + e0);
+                f32x4 nv = sv;
+                if (!frozen) {
+                    f32x4u4 up4 = {0.f, 0.f, 0.f, 0.f}, dn4 = up4;
+                    if (e0 >= W) up4 = *(const f32x4u4 *)(Sp + e0 - W);
+                    if (e0 + 3 + W < DW) dn4 = *(const f32x4u4 *)(Sp + e0 + W);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int e = e0 + i;
+                        const float up =
+                            e < W ? c[3 + e] : (e0 >= W ? up4[i] : Sp[e - W]);
+                        const float dn =
+                            e + W >= DW ? 0.f
+                                        : (e0 + 3 + W < DW ? dn4[i] : Sp[e + W]);
+                        nv[i] = __fadd_rn(__fadd_rn(__fmul_rn(c2, sv[i]),
+                                                    __fmul_rn(c0, up)),
+                                          __fmul_rn(c1, dn));
+                    }
+                }
+                *(f32x4 *)(Sn + e0) = nv;
+            }
+        } else {
+            for (int e = tid; e < DW; e += 512) {
+                const float sv = Sp[e];
+                float nv = sv;
+                if (!frozen) {
+                    const float up = e < W ? c[3 + e] : Sp[e - W];
+                    const float dn = e + W >= DW ? 0.f : Sp[e + W];
+                    nv = __fadd_rn(__fadd_rn(__fmul_rn(c2, sv), __fmul_rn(c0, up)),
+                                   __fmul_rn(c1, dn));
+                }
+                Sn[e] = nv;
+            }
+        }
+    }
+}
+
 // Two 32 KiB stages, two raw barriers per chunk (A: chunk landed, B: fragments
 // read, stage free), one fragment set, accumulators updated in place in two
 // straight loops (input part, hidden part).  Deeper pipelines (3-4 stages, one
@@ -270,6 +407,12 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.su_S && (int)blockIdx.y >= a.su_nbt) {
+        // extra blocks: the step's stack update, off the critical path
+        const int id = ((int)blockIdx.y - a.su_nbt) * gridDim.x + blockIdx.x;
+        cell_fwd_stack_update(a, id * a.su_rows, tid);
+        return;
+    }
     const int j0 = blockIdx.x * CN;
     const int b0 = blockIdx.y * CM;
     const int nchunks = a.nx_chunks + a.nh_chunks;
@@ -311,15 +454,18 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
             const uint32_t dst =
                 lds0 + ((cc % CNSTAGE) * GSTAGE + lw * 8 * 256) * 4u;
             if (lw == 0) {
-                if (c < a.nx_chunks)
-                    glds8(xb + c * (CK * 4), off0, dst);
-                else
+                if (c < a.nx_chunks) {
+                    // (fused stack step: the prologue writes these rows)
+                    if (!a.xt_part) glds8(xb + c * (CK * 4), off0, dst);
+                } else {
                     glds8(hb + (c - a.nx_chunks) * (CK * 4), off1, dst);
+                }
             } else {
                 glds8(wb + c * (CK * 4), off0, dst);
             }
         };
         issue(0); issue(1);
+        if (a.xt_part) cell_fwd_xtop_prologue(a, lds, tid, b0, blockIdx.x);
         for (int k = 0; k < nchunks; ++k) {
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // chunk k landed
             raw_barrier();   // A_k: the consumers may read chunk k
@@ -328,6 +474,7 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
+        if (a.xt_part) cell_fwd_xtop_prologue(a, lds, tid, b0, blockIdx.x);
         int slot[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -1366,6 +1513,8 @@ static int cell_fwd_tile(const CellFwdArgs &a) {
     return narrow ? 16 : 32;
 }
 
+int pcm_cell_fwd_tile(const CellFwdArgs &a) { return cell_fwd_tile(a); }
+
 bool pcm_cell_fwd_writes_ctrl_partials(const CellFwdArgs &a) {
     // only the 32 x 32 kernel's tail computes them
     return a.cs_part && a.H == a.Hn && (a.H % CN) == 0 && 3 + a.cs_W <= 64 &&
@@ -1375,6 +1524,8 @@ bool pcm_cell_fwd_writes_ctrl_partials(const CellFwdArgs &a) {
 int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
     const int nbt = (a.B + CM - 1) / CM;
     const int tile = cell_fwd_tile(a);
+    PCM_REQUIRE(tile == 32 || (!a.su_S && !a.xt_part), PCM_EINVAL,
+                "cell_fwd: the fused stack step needs the 32 x 32 tile");
     if (tile == 64) {
         dim3 grid(a.Hn / LN, (a.B + LM - 1) / LM);
         if (g_pcm_matmul_bf16)
@@ -1389,10 +1540,18 @@ int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
             PCM_LAUNCH(gru_cell_fwd16_kernel<false>, grid, dim3(512), 0, stream, a);
     } else {
         dim3 grid(a.Hn / CN, nbt);
+        if (a.su_S) {
+            // extra block rows: the deferred stack update, su_rows rows per block
+            PCM_REQUIRE(a.su_nbt == nbt && a.su_rows > 0, PCM_EINVAL,
+                        "cell_fwd: bad stack-update arguments");
+            const int ublocks = (a.B + a.su_rows - 1) / a.su_rows;
+            grid.y += (ublocks + grid.x - 1) / grid.x;
+        }
         if (g_pcm_matmul_bf16)
             PCM_LAUNCH(gru_cell_fwd_kernel<true>, grid, dim3(512), 0, stream, a);
         else
             PCM_LAUNCH(gru_cell_fwd_kernel<false>, grid, dim3(512), 0, stream, a);
+        return 0;
     }
     return 0;
 }

@@ -254,13 +254,15 @@ def test_large_stack_gradients_and_limit():
 @pytest.mark.parametrize('env', [
     {'PCM_PERSIST': '1'},
     {'PCM_CHAINS': '2'},
+    {'PCM_FUSE_STACK': '1'},
 ])
 def test_opt_in_recurrence_variants(env):
-    """The two forms of the recurrence that are built but not the default (both
-    measured slower than the launch chain at batch 512): the
+    """The forms of the recurrence that are built but not the default (measured
+    slower than, or level with, the launch chain at batch 512): the
     persistent weight-stationary forward kernel with in-launch group hand-offs
-    (PCM_PERSIST=1) and the batch walked as two half-batch chains on two
-    streams (PCM_CHAINS=2).  The switches are read once per process, hence a
+    (PCM_PERSIST=1), the batch walked as two half-batch chains on two
+    streams (PCM_CHAINS=2) and the stack step fused into the forward cells
+    (PCM_FUSE_STACK=1: two launches per forward step).  The switches are read once per process, hence a
     child process: the full-size training step (every gradient against the
     oracle, with and without dropout), the B=4096 rows and the packed / padded
     data-parallel shard test."""

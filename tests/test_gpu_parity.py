@@ -963,6 +963,8 @@ def test_prepare_batch_on_device_bernoulli():
     {'PCM_FWD_TILE': '16', 'PCM_BWD_XPART': '0', 'PCM_STACK_LEAN': '1'},
     {'PCM_FUSED_CHOOSE': '0', 'PCM_STACK_MFMA': '1'},
     {'PCM_FWD_TILE': '64'},
+    {'PCM_FUSE_STACK': '1'},
+    {'PCM_CTRL_PARTIALS': '0'},
 ])
 def test_alternate_kernel_variants(env):
     """The launchers pick tile widths / kernel variants by shape; the variants
@@ -971,7 +973,9 @@ def test_alternate_kernel_variants(env):
     two-launch output layer + search) are forced through their environment
     switches -- read once per process, hence a child process -- over the
     config-shaped, packed and greedy-decode fixtures (PCM_FWD_TILE=64: the
-    large-batch 64 x 64 forward tile on small ragged batches)."""
+    large-batch 64 x 64 forward tile on small ragged batches; PCM_FUSE_STACK=1:
+    the stack step fused into the cells; PCM_CTRL_PARTIALS=0: the stack step
+    computing its control products itself at every step)."""
     import os
     import subprocess
     import sys
