@@ -130,16 +130,26 @@ class StackGRU(nn.Module):
     def _update_batch_size(self, batch_size: int) -> None:
         """stack_rnn.py:111-129.  ``init_hidden`` / ``init_stack`` stay
         available as attributes; the kernels treat them as implicit zeros."""
+        hidden_shape = (self.n_layers, batch_size, self.rnn_cell_size)
+        stack_shape = (batch_size, self.stack_depth, self.stack_width)
+        device = torch.device(self.device)
+        current = getattr(self, 'init_hidden', None)
+        if (
+            batch_size == getattr(self, 'batch_size', None)
+            and current is not None
+            and tuple(current.shape) == hidden_shape
+            and current.device.type == device.type
+            and tuple(self.init_stack.shape) == stack_shape
+        ):
+            # same size as last time (generate() calls this once per batch):
+            # the zero states are never written to, nothing to rebuild
+            return
         self.batch_size = batch_size
-        self.expected_shape = torch.tensor(
-            [self.n_layers, self.batch_size, self.rnn_cell_size]
-        )
-        self.init_hidden = torch.zeros(
-            self.n_layers, self.batch_size, self.rnn_cell_size
-        ).to(self.device)
-        self.init_stack = torch.zeros(
-            self.batch_size, self.stack_depth, self.stack_width
-        ).to(self.device)
+        self.expected_shape = torch.tensor(list(hidden_shape))
+        # (the reference builds both on the host and copies them over,
+        # 58 MB at batch 4096: 3.7 ms of idle GPU per generate() call)
+        self.init_hidden = torch.zeros(hidden_shape, device=device)
+        self.init_stack = torch.zeros(stack_shape, device=device)
 
     def forward(self, input_token, hidden, stack):
         """One step (stack_rnn.py:131-156): input_token i64[1,B], hidden
