@@ -626,6 +626,40 @@ def test_greedy_decode_matches_oracle(name):
     assert torch.equal(tokens.cpu(), r_tokens)
 
 
+def test_generate_with_changing_batch_sizes():
+    """generate() resizes the decoder per call (stack_rnn.py:111-129); the zero
+    initial states are rebuilt only when the size changes.  One decoder, batch
+    5 -> 3 -> 5 -> 70: every call against the oracle, and the attributes the
+    reference exposes keep the shapes of the last call."""
+    from paccmann_chemistry_amd import GreedySearch
+    p = {
+        'latent_dim': 16, 'rnn_cell_size': 32, 'embedding_size': 20,
+        'vocab_size': 20, 'stack_width': 5, 'stack_depth': 7, 'n_layers': 2,
+        'dropout': 0.0, 'batch_size': 4, 'batch_mode': 'padded',
+        'embedding': 'one_hot', 'use_stack': True, 'bidirectional': False
+    }
+    sd = W.make_state_dict(p, 91)
+    vae = _build_vae(p, sd, train=False)
+    dec = O.sub_params(sd, 'decoder')
+    prime = torch.tensor([2])
+    for call, batch in enumerate((5, 3, 5, 70)):
+        z = torch.from_numpy(np.random.default_rng(92 + call).standard_normal(
+            (batch, p['latent_dim'])).astype(np.float32))
+        tokens = vae.decoder.generate_from_latent(
+            z.unsqueeze(0).to(_dev()), prime.to(_dev()), torch.tensor([3]),
+            search=GreedySearch(), generate_len=9
+        )
+        with torch.no_grad():
+            r_tokens, _ = O.generate_from_latent(
+                dec, z, prime, 9, p['stack_depth'], p['use_stack'])
+        assert torch.equal(tokens.cpu(), r_tokens), batch
+        assert vae.decoder.batch_size == batch
+        assert tuple(vae.decoder.init_hidden.shape) == (2, batch, 32)
+        assert tuple(vae.decoder.init_stack.shape) == (batch, 7, 5)
+        assert vae.decoder.init_hidden.is_cuda
+        assert float(vae.decoder.init_stack.abs().sum()) == 0.0
+
+
 @pytest.mark.parametrize('name', golden_names('beam_'))
 def test_beam_decode_golden(name):
     """generate_from_latent(search=BeamSearch) on the device
