@@ -1236,9 +1236,15 @@ __global__ __launch_bounds__(STHREADS, LEAN ? 4 : 2) void stack_step_fwd_kernel(
 // S_prev -> S_new from global memory (the three taps of an element hit the same
 // lines in L1), with no LDS staging of the stacks and nothing but loads,
 // multiply-adds and stores on the way.
-constexpr int MROWS = 16;
+
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
+// MROWS rows per block.  The MFMA tile holds 16, but 8 rows per block (half the
+// tile empty, twice the blocks: two per CU at 4096 rows) keep more of the update's
+// loads in flight: encoder-only 165.8 k -> 168.2 k molecules/s at batch 4096,
+// greedy decode 186.9 k -> 189.7 k; 4 rows per block: 161.2 k (the weights are
+// read once per block).  PCM_STACK_MROWS = 4 / 8 / 16 forces a value.
+template <int MROWS>
 __global__ __launch_bounds__(512) void stack_step_fwd_mfma_kernel(StackFwdArgs a) {
     __shared__ float part[2][MROWS][65];   // [K half][row][output]
     __shared__ float cu[MROWS][64];        // a[3], v[W] per row
@@ -1281,7 +1287,8 @@ __global__ __launch_bounds__(512) void stack_step_fwd_mfma_kernel(StackFwdArgs a
         }
         // D[i][j]: lane holds rows i = 4 g + e, column j = r16
 #pragma unroll
-        for (int e = 0; e < 4; ++e) part[kh][4 * g + e][ct * 16 + r16] = acc[e];
+        for (int e = 0; e < 4; ++e)
+            if (4 * g + e < MROWS) part[kh][4 * g + e][ct * 16 + r16] = acc[e];
     }
     __syncthreads();
     for (int idx = tid; idx < MROWS * 64; idx += 512) {
@@ -1594,9 +1601,20 @@ int pcm_launch_stack_fwd(const StackFwdArgs &a, hipStream_t stream) {
     }();
     if (a.B >= mfma_rows && (a.H % 32) == 0 && (a.Hp % 4) == 0 &&
         3 + a.W <= 64 && ((a.D * a.W) & 3) == 0 && a.AVW <= 64) {
-        PCM_LAUNCH(stack_step_fwd_mfma_kernel,
-                           dim3((a.B + MROWS - 1) / MROWS), dim3(512), 0, stream,
-                           a);
+        static const int mrows = [] {
+            const char *e = getenv("PCM_STACK_MROWS");
+            const int v = e ? atoi(e) : 8;
+            return (v == 16 || v == 4) ? v : 8;
+        }();
+        if (mrows == 4)
+            PCM_LAUNCH(stack_step_fwd_mfma_kernel<4>, dim3((a.B + 3) / 4),
+                       dim3(512), 0, stream, a);
+        else if (mrows == 8)
+            PCM_LAUNCH(stack_step_fwd_mfma_kernel<8>, dim3((a.B + 7) / 8),
+                       dim3(512), 0, stream, a);
+        else
+            PCM_LAUNCH(stack_step_fwd_mfma_kernel<16>, dim3((a.B + 15) / 16),
+                       dim3(512), 0, stream, a);
         return 0;
     }
     // (two rows per block only while both fit the LDS row cache)
