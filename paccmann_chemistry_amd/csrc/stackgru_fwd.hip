@@ -870,12 +870,25 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd64_kernel(CellFwdArgs a) {
     // batch row (r & 3) + 8 (r >> 2) + 4 lh of the quadrant
     const int j = j0 + 32 * ch + lrow;
     if (j >= a.H) return;
+    // in groups of eight: all of a group's operand loads are requested before
+    // its first store (an element at a time, every element's loads queue behind
+    // the stores of the one before: 16 memory round trips per lane)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int b = b0 + 32 * rh + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (b >= a.B) continue;
-        const float s[4] = {acc_r[r], acc_z[r], acc_ni[r], acc_nh[r]};
-        cell_fwd_element(a, b, j, s);
+    for (int g8 = 0; g8 < 2; ++g8) {
+        CellFwdOut out[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 8 * g8 + i;
+            const int b = b0 + 32 * rh + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float s[4] = {acc_r[r], acc_z[r], acc_ni[r], acc_nh[r]};
+            if (b < a.B) out[i] = cell_fwd_math(a, b, j, s);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = 8 * g8 + i;
+            const int b = b0 + 32 * rh + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (b < a.B) cell_fwd_store(a, b, j, out[i]);
+        }
     }
 }
 
