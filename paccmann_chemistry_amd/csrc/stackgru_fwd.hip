@@ -401,7 +401,9 @@ __device__ __forceinline__ void cell_fwd_stack_update(const CellFwdArgs &a,
 constexpr int CNSTAGE = 2;
 static_assert(CNSTAGE * GSTAGE >= 4 * 4 * 1024, "reduction buffer must fit");
 
-template <bool BF16>
+// XT: with the stack step's prologue (CellFwdArgs::xt_*, opt-in) -- a separate
+// instantiation, so that the default kernel does not carry its registers.
+template <bool BF16, bool XT>
 __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[CNSTAGE * GSTAGE];
     const int tid = threadIdx.x;
@@ -426,7 +428,6 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
     }
     f32x4 wf[2];
     cell_fwd_ctrl_frags(a, wave, lane, j0, wf);
-
     if (wave >= 4) {
         // loaders: same lane -> (row, swizzled granule) map as above
         const int lw = wave - 4;
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
             if (lw == 0) {
                 if (c < a.nx_chunks) {
                     // (fused stack step: the prologue writes these rows)
-                    if (!a.xt_part) glds8(xb + c * (CK * 4), off0, dst);
+                    if (!XT) glds8(xb + c * (CK * 4), off0, dst);
                 } else {
                     glds8(hb + (c - a.nx_chunks) * (CK * 4), off1, dst);
                 }
@@ -465,7 +466,8 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
             }
         };
         issue(0); issue(1);
-        if (a.xt_part) cell_fwd_xtop_prologue(a, lds, tid, b0, blockIdx.x);
+        if constexpr (XT)
+            cell_fwd_xtop_prologue(a, lds, tid, b0, blockIdx.x);
         for (int k = 0; k < nchunks; ++k) {
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // chunk k landed
             raw_barrier();   // A_k: the consumers may read chunk k
@@ -474,7 +476,8 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
-        if (a.xt_part) cell_fwd_xtop_prologue(a, lds, tid, b0, blockIdx.x);
+        if constexpr (XT)
+            cell_fwd_xtop_prologue(a, lds, tid, b0, blockIdx.x);
         int slot[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -1567,10 +1570,20 @@ int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
             const int ublocks = (a.B + a.su_rows - 1) / a.su_rows;
             grid.y += (ublocks + grid.x - 1) / grid.x;
         }
-        if (g_pcm_matmul_bf16)
-            PCM_LAUNCH(gru_cell_fwd_kernel<true>, grid, dim3(512), 0, stream, a);
-        else
-            PCM_LAUNCH(gru_cell_fwd_kernel<false>, grid, dim3(512), 0, stream, a);
+        if (a.xt_part) {
+            if (g_pcm_matmul_bf16)
+                PCM_LAUNCH((gru_cell_fwd_kernel<true, true>), grid, dim3(512), 0,
+                           stream, a);
+            else
+                PCM_LAUNCH((gru_cell_fwd_kernel<false, true>), grid, dim3(512),
+                           0, stream, a);
+        } else if (g_pcm_matmul_bf16) {
+            PCM_LAUNCH((gru_cell_fwd_kernel<true, false>), grid, dim3(512), 0,
+                       stream, a);
+        } else {
+            PCM_LAUNCH((gru_cell_fwd_kernel<false, false>), grid, dim3(512), 0,
+                       stream, a);
+        }
         return 0;
     }
     return 0;
