@@ -247,8 +247,47 @@ def packed_to_lengths(packed):
             raise ValueError(
                 'PackedSequence must be built from length-sorted sequences'
             )
-    padded, lengths = pad_packed_sequence(packed)
-    return padded, lengths
+    return _unpack_sorted(packed)
+
+
+_UNPACK_CACHE = {}
+
+
+def _unpack_sorted(packed):
+    """``pad_packed_sequence`` for a length-sorted PackedSequence without its
+    loop over the time steps (one slice copy per step: 120 tiny copies per
+    sequence tensor at T=120): ``data`` is row-major over (t, b < batch_sizes[t]),
+    so the padded tensor is ONE gather through an index built from
+    ``batch_sizes`` on the host.  The index is kept for the next call (encoder
+    input, decoder input and target of a batch share their ``batch_sizes``)."""
+    sizes = packed.batch_sizes
+    steps, batch = int(sizes.numel()), int(sizes[0])
+    device = packed.data.device
+    key = (device.type, device.index)
+    cached = _UNPACK_CACHE.get(key)
+    if cached is None or not torch.equal(cached[0], sizes):
+        offsets = torch.cumsum(sizes, 0) - sizes
+        cols = torch.arange(batch).view(1, -1)
+        valid = cols < sizes.view(-1, 1)
+        index = (offsets.view(-1, 1) + cols).masked_fill(~valid, 0)
+        lengths = valid.sum(dim=0)
+        if device.type == 'cuda':
+            n = index.numel()
+            staged = _stage_to_device(
+                [index.reshape(-1), valid.reshape(-1).to(torch.int64)], device
+            )
+            index_d, valid_d = staged[:n], staged[n:].bool()
+        else:
+            index_d, valid_d = index.reshape(-1), valid.reshape(-1)
+        cached = (sizes.clone(), index_d, valid_d, lengths)
+        _UNPACK_CACHE[key] = cached
+    _, index, valid, lengths = cached
+    data = packed.data
+    padded = data[index].view(steps, batch, *data.shape[1:])
+    mask = valid.view(steps, batch, *([1] * (data.dim() - 1)))
+    padded = torch.where(mask, padded, torch.zeros((), dtype=data.dtype,
+                                                   device=device))
+    return padded, lengths.clone()
 
 
 def to_np(x):
