@@ -884,10 +884,21 @@ int pcm_stackgru_backward(const pcm_dims *dims,
         int r;
         GemmBatch gb;
         gb.count = 0;
+        // packed mode: the products below skip the 16-row chunks no sequence
+        // reaches (PCM_ROW_SKIP=0: multiply the zeros, as in padded mode)
+        static const bool row_skip_enabled = [] {
+            const char *e = getenv("PCM_ROW_SKIP");
+            return !e || atoi(e) != 0;
+        }();
+        GemmRowSkip skip;
+        const bool use_skip =
+            row_skip_enabled && active_rows &&
+            pcm_gemm_row_skip(active_rows + t_lo, t_hi - t_lo, B, &skip);
         auto flush = [&]() -> int {
             if (gb.count == 0) return PCM_OK;
             pcm_probe_begin(PCM_K_DW_GEMM);
-            int q = pcm_gemm_launch(gb, gs2, gsb, gst);
+            int q = pcm_gemm_launch(gb, gs2, gsb, gst,
+                                    use_skip ? &skip : nullptr);
             pcm_probe_end(PCM_K_DW_GEMM);
             gb.count = 0;
             return q;

@@ -58,11 +58,30 @@ struct GemmBatch {
     int count;
 };
 
+// Rows of a time-major [steps][batch] reduction that are known to be zero: in
+// packed mode step t only has its first active rows filled, the rest of its
+// batch block holds zeros.  cum[t] = number of 16-row chunks with at least one
+// active row in steps [0, t); chunk j of step t is active iff j < cum[t+1] -
+// cum[t].  The K-major kernel then walks the active chunks only (every
+// problem of the batch must have K == steps * cps * 16).
+#define PCM_SKIP_MAX_STEPS 256
+struct GemmRowSkip {
+    int steps;
+    int cps;                                   // chunks per step (batch / 16)
+    unsigned short cum[PCM_SKIP_MAX_STEPS + 1];
+};
+// false when the shape does not fit the descriptor (the caller then passes none)
+bool pcm_gemm_row_skip(const int32_t *active_rows, int steps, int batch,
+                       GemmRowSkip *out);
+
 // Bytes of split-K slab scratch pcm_gemm_launch may need for this batch.
 size_t pcm_gemm_scratch_bytes(const GemmBatch &batch);
 // Launch a grouped GEMM.  scratch may be NULL (then no split-K is used).
+// skip (nullable) is honoured by the K-major kernel only; the generic kernels
+// multiply the zero rows.
 int pcm_gemm_launch(const GemmBatch &batch, void *scratch,
-                    size_t scratch_bytes, hipStream_t stream);
+                    size_t scratch_bytes, hipStream_t stream,
+                    const GemmRowSkip *skip = nullptr);
 
 // true if pcm_gemm_launch will run this batch on the K-major kernel, the only
 // one that honours GemmProb::colsum1/2

@@ -7,6 +7,7 @@
 // and, in the reverse recurrence, the per-step dgates.W products.
 #include <algorithm>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -196,11 +197,14 @@ struct TileMap {
 // BF16: operands rounded to bf16 in registers, one v_mfma_f32_32x32x16_bf16 per
 // sub-tile and chunk (lane half lk holds k = lk, lk + 2, ... of the chunk for
 // both operands); the column sums stay fp32 sums of the unrounded values.
-template <int FIXED_MODE, bool BF16 = false>
+// SKIP: the reduction walks the active 16-row chunks of a GemmRowSkip only.
+struct NoSkip {};
+template <int FIXED_MODE, bool BF16 = false, bool SKIP = false>
 __global__ __launch_bounds__(256, FIXED_MODE == 0 ? 3 : 2) void gemm_tn_kernel(GemmBatch batch,
                                                          int splits, float *slab,
                                                          SlabInfo slabs,
-                                                         TileMap tm) {
+                                                         TileMap tm,
+                                                         std::conditional_t<SKIP, GemmRowSkip, NoSkip> rs) {
     __shared__ __attribute__((aligned(16))) float As[2][BK * TN_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * TN_LD];
     const int ntiles = tm.first[batch.count];
@@ -221,7 +225,8 @@ __global__ __launch_bounds__(256, FIXED_MODE == 0 ? 3 : 2) void gemm_tn_kernel(G
     const int tmi = tl / tm.tiles_n[pz];
     const int m0 = tmi * 128, n0 = (tl - tmi * tm.tiles_n[pz]) * 128;
 
-    const int nchunks = p.K / BK;
+    int nchunks = p.K / BK;
+    if constexpr (SKIP) nchunks = rs.cum[rs.steps];
     const int cps = (nchunks + splits - 1) / splits;
     const int c0 = sk * cps;
     const int c1 = min(nchunks, c0 + cps);
@@ -257,8 +262,31 @@ __global__ __launch_bounds__(256, FIXED_MODE == 0 ? 3 : 2) void gemm_tn_kernel(G
         const int lofs = k_a * TN_LD + 4 * q_a;
         const int last = c1 - 1;
         f32x4 ra[2][2], rb[2][2];
+        // SKIP: load_chunk is called with c0, c0 + 1, ... in order; (w_t, w_j)
+        // is the step and the chunk inside it of the next active chunk
+        int w_t = 0, w_j = 0, w_n = 0, w_c = c0;
+        if constexpr (SKIP) {
+            int lo = 0, hi = rs.steps;       // last t with cum[t] <= c0
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if ((int)rs.cum[mid] <= c0) lo = mid; else hi = mid;
+            }
+            w_t = lo;
+            w_j = c0 - (int)rs.cum[lo];
+            w_n = (int)rs.cum[lo + 1] - (int)rs.cum[lo];
+        }
         auto load_chunk = [&](int c, f32x4 (&qa)[2], f32x4 (&qb)[2]) {
             c = min(c, last);  // the tail re-reads the last chunk (never stored)
+            if constexpr (SKIP) {
+                c = w_t * rs.cps + w_j;
+                if (w_c < last) {
+                    ++w_c;
+                    if (++w_j == w_n) {   // counts never grow: no empty step
+                        ++w_t; w_j = 0;   // before the last active chunk
+                        w_n = (int)rs.cum[w_t + 1] - (int)rs.cum[w_t];
+                    }
+                }
+            }
             const float *pa = ga + (long long)c * BK * p.a_cs;
             const float *pb = gb + (long long)c * BK * p.b_rs;
             qa[0] = *(const f32x4 *)pa;
@@ -541,8 +569,30 @@ size_t pcm_gemm_scratch_bytes(const GemmBatch &batch) {
     return total * sizeof(float);
 }
 
+bool pcm_gemm_row_skip(const int32_t *active_rows, int steps, int batch,
+                       GemmRowSkip *out) {
+    if (!active_rows || steps < 1 || steps > PCM_SKIP_MAX_STEPS || (batch % BK))
+        return false;
+    if ((long long)steps * (batch / BK) > 65535) return false;
+    out->steps = steps;
+    out->cps = batch / BK;
+    int cum = 0, prev = batch;
+    for (int t = 0; t < steps; ++t) {
+        const int rows = active_rows[t];
+        if (rows < 0 || rows > prev) return false;   // must not grow
+        prev = rows;
+        out->cum[t] = (unsigned short)cum;
+        cum += (rows + BK - 1) / BK;
+    }
+    for (int t = steps; t <= PCM_SKIP_MAX_STEPS; ++t)
+        out->cum[t] = (unsigned short)cum;
+    // worth it from a tenth of the rows on; an empty reduction keeps the plain
+    // path (which writes the zeros / keeps the accumulators)
+    return cum > 0 && cum * 10 <= steps * (batch / BK) * 9;
+}
+
 int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
-                    hipStream_t stream) {
+                    hipStream_t stream, const GemmRowSkip *skip) {
     PCM_REQUIRE(batch.count >= 1 && batch.count <= PCM_GEMM_MAX_PROBS,
                 PCM_EINVAL, "gemm: bad problem count %d", batch.count);
     for (int i = 0; i < batch.count; ++i) {
@@ -557,6 +607,13 @@ int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
     }
     Plan pl = make_plan(batch, scratch != nullptr);
     const bool use_tn = tn_eligible(batch) && (pl.big || tn_long_k(batch));
+    if (skip && use_tn)
+        for (int i = 0; i < batch.count; ++i)
+            PCM_REQUIRE(batch.p[i].K == skip->steps * skip->cps * BK, PCM_EINVAL,
+                        "gemm: row-skip descriptor covers %d rows, problem %d "
+                        "has K=%d", skip->steps * skip->cps * BK, i,
+                        batch.p[i].K);
+    if (!use_tn) skip = nullptr;
     TileMap tmap;
     long long tn_tiles = 0;
     if (use_tn) {
@@ -575,6 +632,7 @@ int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
         bool wide_batch = true;
         for (int i = 0; i < batch.count; ++i)
             wide_batch = wide_batch && batch.p[i].M > 64 && batch.p[i].N > 64;
+        if (skip) minK = (int)skip->cum[skip->steps] * BK;
         pl.splits = scratch ? tn_splits(batch, tn_tiles, minK, wide_batch,
                                         scratch_bytes)
                             : 1;
@@ -608,18 +666,31 @@ int pcm_gemm_launch(const GemmBatch &batch, void *scratch, size_t scratch_bytes,
         // the weight-gradient probe (id 6) times the wide launches only (a
         // cleared start event makes pcm_probe_end_ drop the pair)
         if (!wide && g_pcm_probe_id == PCM_K_DW_GEMM) g_pcm_probe_start = nullptr;
-        if (wide && g_pcm_matmul_bf16)
+        const NoSkip ns;
+        if (skip && wide && g_pcm_matmul_bf16)
+            PCM_LAUNCH((gemm_tn_kernel<0, true, true>), tn_grid, dim3(256),
+                               g_pcm_gemm_lds_pad, stream, batch, pl.splits,
+                               slab, slabs, tmap, *skip);
+        else if (skip && wide)
+            PCM_LAUNCH((gemm_tn_kernel<0, false, true>), tn_grid, dim3(256),
+                               g_pcm_gemm_lds_pad, stream, batch, pl.splits,
+                               slab, slabs, tmap, *skip);
+        else if (skip)
+            PCM_LAUNCH((gemm_tn_kernel<-1, false, true>), tn_grid, dim3(256),
+                               g_pcm_gemm_lds_pad, stream, batch, pl.splits,
+                               slab, slabs, tmap, *skip);
+        else if (wide && g_pcm_matmul_bf16)
             PCM_LAUNCH((gemm_tn_kernel<0, true>), tn_grid, dim3(256),
                                g_pcm_gemm_lds_pad, stream, batch, pl.splits,
-                               slab, slabs, tmap);
+                               slab, slabs, tmap, ns);
         else if (wide)
             PCM_LAUNCH(gemm_tn_kernel<0>, tn_grid, dim3(256),
                                g_pcm_gemm_lds_pad, stream, batch, pl.splits,
-                               slab, slabs, tmap);
+                               slab, slabs, tmap, ns);
         else
             PCM_LAUNCH(gemm_tn_kernel<-1>, tn_grid, dim3(256),
                                g_pcm_gemm_lds_pad, stream, batch, pl.splits,
-                               slab, slabs, tmap);
+                               slab, slabs, tmap, ns);
     } else if (pl.big)
         hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), g_pcm_gemm_lds_pad,
                            stream,

@@ -108,6 +108,66 @@ def test_full_size_training_step_matches_oracle(dropout):
     assert not bad, bad
 
 
+def test_packed_training_step_matches_oracle():
+    """Packed mode at a batch the K-major weight-gradient kernel takes (B=256,
+    T=48, lengths 2..48, batch_sizes shrinking to 3 rows): the launches walk
+    the still-running prefix of the batch and the weight-gradient products
+    skip the 16-row chunks no sequence reaches (PCM_ROW_SKIP=0 multiplies the
+    zeros instead; test_opt_in_recurrence_variants runs this test that way).
+    Loss, mu, logits of the real steps and every gradient against the oracle's
+    packed semantics (vae.py:138-236, 352-389)."""
+    from paccmann_chemistry_amd import vae_loss_function
+    batch, steps = 256, 48
+    p = dict(CONFIG, batch_size=batch, batch_mode='packed')
+    sd = W.make_state_dict(p, 4150)
+    tokens = W.synthetic_tokens(steps, batch, p['vocab_size'], 4151)
+    targets = W.shifted_targets(tokens)
+    rng = np.random.default_rng(4152)
+    lens = np.sort(rng.integers(2, steps + 1, size=batch))[::-1].copy()
+    lens[:3] = steps
+    lengths = torch.from_numpy(lens.astype(np.int64))
+    eps = torch.from_numpy(np.random.default_rng(4153).standard_normal(
+        (batch, p['latent_dim'])).astype(np.float32))
+    vae = _build_vae(p, sd)
+    dev = _dev()
+    pack = torch.nn.utils.rnn.pack_sequence
+
+    def packed(x):
+        return pack([x[:n, b] for b, n in enumerate(lens.tolist())]).to(dev)
+
+    dec_loss, mu, logvar = vae(packed(tokens), packed(tokens), packed(targets),
+                               eps=eps.to(dev))
+    total, _ = vae_loss_function(dec_loss, mu, logvar, kl_growth=0.003,
+                                 step=5000)
+    total.backward()
+    vae.check_tokens()
+
+    ref = {k: v.clone().requires_grad_('embedding' not in k)
+           for k, v in sd.items()}
+    r_mu, r_logvar = O.encoder_forward(
+        O.sub_params(ref, 'encoder'), tokens, p['stack_depth'], lengths)
+    z = O.reparameterize(r_mu, r_logvar, eps)
+    r_loss, r_logits, _ = O.decoder_forward(
+        O.sub_params(ref, 'decoder'), z, tokens, targets, p['stack_depth'],
+        lengths)
+    r_total, _ = O.vae_loss(r_loss, r_mu, r_logvar, 0.003, step=5000)
+    r_total.backward()
+
+    assert _rel_to_max(mu, r_mu) < 1e-5
+    active = (lengths.view(1, -1) > torch.arange(steps).view(-1, 1))
+    assert _rel_to_max(vae.decoder.logits.detach().cpu() * active.unsqueeze(-1),
+                       r_logits.detach() * active.unsqueeze(-1)) < LOGIT_TOL
+    assert abs(total.item() - r_total.item()) < 1e-5 * abs(r_total.item())
+    bad = {}
+    for name, param in vae.named_parameters():
+        if ref[name].grad is None:
+            continue
+        err = _rel_to_max(param.grad, ref[name].grad)
+        if not err < GRAD_TOL:
+            bad[name] = err
+    assert not bad, bad
+
+
 def test_sampling_tokens_bit_exact_against_oracle_distribution():
     """SamplingSearch.step at the config model (V=60, H=512), B=70: the device
     draw is a counter hash of (seed, step, row); with the same uniforms the
@@ -255,6 +315,7 @@ def test_large_stack_gradients_and_limit():
     {'PCM_PERSIST': '1'},
     {'PCM_CHAINS': '2'},
     {'PCM_FUSE_STACK': '1'},
+    {'PCM_ROW_SKIP': '0'},
 ])
 def test_opt_in_recurrence_variants(env):
     """The forms of the recurrence that are built but not the default (measured
@@ -262,7 +323,8 @@ def test_opt_in_recurrence_variants(env):
     persistent weight-stationary forward kernel with in-launch group hand-offs
     (PCM_PERSIST=1), the batch walked as two half-batch chains on two
     streams (PCM_CHAINS=2) and the stack step fused into the forward cells
-    (PCM_FUSE_STACK=1: two launches per forward step).  The switches are read once per process, hence a
+    (PCM_FUSE_STACK=1: two launches per forward step); PCM_ROW_SKIP=0 is the
+    packed-mode weight-gradient reduction over all rows, zeros included.  The switches are read once per process, hence a
     child process: the full-size training step (every gradient against the
     oracle, with and without dropout), the B=4096 rows and the packed / padded
     data-parallel shard test."""
@@ -274,7 +336,7 @@ def test_opt_in_recurrence_variants(env):
            os.path.join(ROOT, 'tests', 'test_gpu_fullsize.py'),
            os.path.join(ROOT, 'tests', 'test_gpu_parity.py'), '-k',
            'full_size_training or batch_4096 or shards_sum or determinism or '
-           'vae_config_golden']
+           'vae_config_golden or packed_training_step']
     res = subprocess.run(cmd, env=dict(os.environ, **env), cwd=ROOT,
                          capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
