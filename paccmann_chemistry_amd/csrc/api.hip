@@ -290,7 +290,7 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
                         const int32_t *lengths, int t, float drop_p,
                         uint64_t seed, int32_t *status, hipStream_t st,
                         int rows = -1, int b0 = 0, float *cs_part = nullptr,
-                        bool *have_part = nullptr) {
+                        int *have_part = nullptr) {
     // cs_part / have_part: the top layer's forward cell may leave partial sums
     // of the next step's stack controls (see CellFwdArgs); *have_part says, on
     // entry, that the previous step left them for (at least) these rows, and on
@@ -319,7 +319,7 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
     }();
     bool fuse = false;
     if (fuse_enabled && lay.use_stack && lay.L >= 2 && cs_part && have_part &&
-        *have_part && lay.Kxp[0] == 64 && lay.Wp == 64 && lay.AVW <= 64 &&
+        *have_part == lay.Hn / 32 && lay.Kxp[0] == 64 && lay.Wp == 64 && lay.AVW <= 64 &&
         3 + lay.W <= 64 && lay.H == lay.Hn) {
         CellFwdArgs probe;
         memset(&probe, 0, sizeof(probe));
@@ -337,7 +337,7 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
         s.cs_part = (cs_part && have_part && *have_part)
                         ? cs_part + (size_t)b0 * (lay.Hn / 32) * 64 : nullptr;
-        s.cs_parts = lay.Hn / 32;
+        s.cs_parts = have_part ? *have_part : 0;
         pcm_probe_begin(PCM_K_STACK_FWD);
         int rc = pcm_launch_stack_fwd(s, st);
         pcm_probe_end(PCM_K_STACK_FWD);
@@ -379,16 +379,17 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
             c.su_D = lay.D; c.su_W = lay.W; c.su_AVW = lay.AVW;
         }
         if (l == lay.L - 1 && have_part) {
-            *have_part = false;
+            *have_part = 0;
             if (cs_part && lay.use_stack && 3 + lay.W <= 64) {
                 c.cs_ctrl_w = w->ctrl_w; c.cs_push_w = w->push_w;
-                c.cs_part = cs_part + (size_t)b0 * (lay.Hn / 32) * 64;
+                c.cs_part = cs_part;
                 c.cs_W = lay.W;
-                if (pcm_cell_fwd_writes_ctrl_partials(c)) {
-                    *have_part = true;
-                } else {
-                    c.cs_part = nullptr;
-                }
+                // partials per row: one per column tile of THIS launch's tile
+                // width; a chain's slice starts at the widest layout's offset
+                *have_part = pcm_cell_fwd_ctrl_partials(c);
+                c.cs_part = *have_part
+                                ? cs_part + (size_t)b0 * (lay.Hn / 32) * 64
+                                : nullptr;
             }
         }
         pcm_probe_begin(PCM_K_CELL_FWD, l);
@@ -704,7 +705,7 @@ int pcm_stackgru_forward(const pcm_dims *dims,
     }();
     float *cs_part = (ctrl_partials && lay.use_stack) ? sv + lay.off_cspart
                                                       : nullptr;
-    bool have_part[2] = {false, false};
+    int have_part[2] = {0, 0};
     for (int t = 0; t < steps && !persist; ++t) {
         StepBufs sb;
         memset(&sb, 0, sizeof(sb));
@@ -1398,7 +1399,7 @@ struct GenLayout {
     SGLayout lay;
     size_t off_h[2][PCM_MAX_LAYERS];
     size_t off_S[2];
-    size_t off_av, off_xtop, off_tokg, off_logits, off_tok;
+    size_t off_av, off_xtop, off_tokg, off_logits, off_tok, off_cspart;
     size_t off_wpack[PCM_MAX_LAYERS], off_bpack[PCM_MAX_LAYERS];
     size_t total;
 };
@@ -1418,6 +1419,8 @@ static int gen_layout(const pcm_dims *dims, GenLayout *g) {
     g->off_tokg = take(off, (size_t)lay.V * 3 * lay.Hn);
     g->off_logits = take(off, (size_t)lay.B * lay.V);
     g->off_tok = take(off, (size_t)lay.B * 2);  // int64[B]
+    g->off_cspart =
+        take(off, lay.use_stack ? (size_t)lay.B * (lay.Hn / 32) * 64 : 0);
     for (int l = 0; l < lay.L; ++l) {
         g->off_wpack[l] = take(off, (size_t)3 * lay.Hn * lay.Kp[l]);
         g->off_bpack[l] = take(off, (size_t)4 * lay.Hn);
@@ -1505,6 +1508,15 @@ int pcm_stackgru_generate(const pcm_dims *dims,
 
     const int total_steps = (prime_len - 1) + generate_len;
     int slot = 0;
+    // partial stack-control sums from a step's top cell to the next step's
+    // stack kernel, as in pcm_stackgru_forward
+    static const bool ctrl_partials = [] {
+        const char *e = getenv("PCM_CTRL_PARTIALS");
+        return !e || atoi(e) != 0;
+    }();
+    float *cs_part = (ctrl_partials && lay.use_stack) ? ws + g.off_cspart
+                                                      : nullptr;
+    int have_part = 0;
     for (int s = 0; s < total_steps; ++s) {
         const bool priming = s < prime_len - 1;
         if (s < prime_len)
@@ -1523,7 +1535,8 @@ int pcm_stackgru_generate(const pcm_dims *dims,
         }
         sb.tok = cur_tok;
         rc = enqueue_step(lay, weights, ws + g.off_tokg, wpack, bpack, sb,
-                          nullptr, s, 0.f, 0, status, st);
+                          nullptr, s, 0.f, 0, status, st, -1, 0, cs_part,
+                          &have_part);
         if (rc) return rc;
         slot ^= 1;
         if (!priming) {

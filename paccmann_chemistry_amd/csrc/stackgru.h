@@ -109,7 +109,8 @@ int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream);
 // step (xt_*, su_*) lives in the 32 x 32 kernel only
 int pcm_cell_fwd_tile(const CellFwdArgs &a);
 // true when pcm_launch_cell_fwd will run `a` on the kernel that writes cs_part
-bool pcm_cell_fwd_writes_ctrl_partials(const CellFwdArgs &a);
+// number of control partials per row this launch would write (0: none)
+int pcm_cell_fwd_ctrl_partials(const CellFwdArgs &a);
 
 struct StackFwdArgs {
     const float *htop;   // [B, Hp] top-layer hidden before the step

@@ -808,6 +808,9 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd64_kernel(CellFwdArgs a) {
             issue(k + 2);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // C: the tail's re-issued chunks have landed, the consumers may reuse
+        // the stages for the control partials
+        if (a.cs_part) raw_barrier();
         return;
     }
 
@@ -872,7 +875,18 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd64_kernel(CellFwdArgs a) {
     // gate math straight from the accumulators: lane = hidden unit, register r =
     // batch row (r & 3) + 8 (r >> 2) + 4 lh of the quadrant
     const int j = j0 + 32 * ch + lrow;
-    if (j >= a.H) return;
+    if (j >= a.H) return;   // (never with cs_part: the launcher wants H == Hn)
+    // Top layer with a stack (cs_part): the block's 64 x 64 tile of new hidden
+    // states is parked in LDS (row stride HT) and multiplied with the [64 k x 64
+    // outputs] block of [Wc ; Ws]: this column tile's share of the NEXT stack
+    // step's 3 + W control / push pre-activations (partial number blockIdx.x of
+    // Hn / 64, summed in order by the stack kernel, which then no longer
+    // streams [Wc ; Ws] and the hidden rows: 13 of its 31 us at 4096 rows).
+    // Wave (rh, ch): rows 32 rh.., outputs 32 ch.., 32x32x2 MFMAs with
+    // instruction i of lane half lh taking k = 32 lh + i.
+    constexpr int HT = 68;
+    const bool ctrl = a.cs_part != nullptr;
+    f32x4 wv[8];
     // in groups of eight: all of a group's operand loads are requested before
     // its first store (an element at a time, every element's loads queue behind
     // the stores of the one before: 16 memory round trips per lane)
@@ -884,7 +898,23 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd64_kernel(CellFwdArgs a) {
             const int r = 8 * g8 + i;
             const int b = b0 + 32 * rh + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const float s[4] = {acc_r[r], acc_z[r], acc_ni[r], acc_nh[r]};
+            out[i].hn = 0.f;
             if (b < a.B) out[i] = cell_fwd_math(a, b, j, s);
+        }
+        if (ctrl && g8 == 1) {
+            // (requested once the accumulators are dead: 32 registers)
+            const int o = 32 * ch + lrow;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (o < 3 + a.cs_W) {
+                const float *wrow =
+                    (o < 3 ? a.cs_ctrl_w + (long long)o * a.H
+                           : a.cs_push_w + (long long)(o - 3) * a.H) +
+                    j0 + 32 * lh;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    wv[q] = *(const f32x4a4 *)(wrow + 4 * q);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -892,6 +922,37 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd64_kernel(CellFwdArgs a) {
             const int b = b0 + 32 * rh + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (b < a.B) cell_fwd_store(a, b, j, out[i]);
         }
+        if (ctrl) {
+            if (g8 == 0) raw_barrier();   // C (see the loaders)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = 8 * g8 + i;
+                const int row = 32 * rh + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                lds[row * HT + 32 * ch + lrow] = out[i].hn;
+            }
+        }
+    }
+    if (!ctrl) return;
+    raw_barrier();   // D: the tile is complete (consumer waves only by now)
+    f32x16 pacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pacc[r] = 0.f;
+    const float *trow = lds + (32 * rh + lrow) * HT + 32 * lh;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x4 fa = *(const f32x4 *)(trow + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], wv[q][e], pacc, 0,
+                                                        0, 0);
+    }
+    const int parts = a.Hn / LN;
+    float *dst = a.cs_part + ((long long)b0 * parts + blockIdx.x) * 64 + 32 * ch +
+                 lrow;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = 32 * rh + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (b0 + row < a.B) dst[(long long)row * parts * 64] = pacc[r];
     }
 }
 
@@ -1268,7 +1329,37 @@ __global__ __launch_bounds__(512) void stack_step_fwd_mfma_kernel(StackFwdArgs a
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b0 = blockIdx.x * MROWS;
-    {
+    if (a.cs_part) {
+        // the previous step's top cell left partial sums of the pre-activations
+        // (one per column tile of its launch): sum them in order
+        for (int idx = tid; idx < MROWS * 64; idx += 512) {
+            const int r = idx >> 6, o = idx & 63;
+            const float *src =
+                a.cs_part + (long long)min(b0 + r, a.B - 1) * a.cs_parts * 64 + o;
+            float v = 0.f;
+            if (o < NO) {
+                float pv[16];
+                int p = 0;
+                for (; p + 16 <= a.cs_parts; p += 16) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) pv[i] = src[(p + i) * 64];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v += pv[i];
+                }
+                for (; p + 8 <= a.cs_parts; p += 8) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pv[i] = src[(p + i) * 64];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v += pv[i];
+                }
+                for (; p < a.cs_parts; ++p) v += src[p * 64];
+                v += o < 3 ? a.ctrl_b[o] : a.push_b[o - 3];
+                if (o >= 3) v = tanhf(v);
+            }
+            cu[r][o] = v;
+        }
+    } else {
+        {
         const int r16 = lane & 15, g = lane >> 4;
         const int ct = wave & 3, kh = wave >> 2;
         const int o = min(ct * 16 + r16, NO - 1);
@@ -1316,6 +1407,7 @@ __global__ __launch_bounds__(512) void stack_step_fwd_mfma_kernel(StackFwdArgs a
             if (o >= 3) v = tanhf(v);
         }
         cu[r][o] = v;
+    }
     }
     __syncthreads();
     if (tid < MROWS) {
@@ -1538,10 +1630,14 @@ static int cell_fwd_tile(const CellFwdArgs &a) {
 
 int pcm_cell_fwd_tile(const CellFwdArgs &a) { return cell_fwd_tile(a); }
 
-bool pcm_cell_fwd_writes_ctrl_partials(const CellFwdArgs &a) {
-    // only the 32 x 32 kernel's tail computes them
-    return a.cs_part && a.H == a.Hn && (a.H % CN) == 0 && 3 + a.cs_W <= 64 &&
-           cell_fwd_tile(a) == 32;
+int pcm_cell_fwd_ctrl_partials(const CellFwdArgs &a) {
+    // the 32 x 32 and the 64 x 64 kernels' tails compute them: one partial per
+    // column tile (0: this launch writes none)
+    if (!a.cs_part || a.H != a.Hn || 3 + a.cs_W > 64) return 0;
+    const int tile = cell_fwd_tile(a);
+    if (tile == 32 && (a.H % CN) == 0) return a.Hn / CN;
+    if (tile == 64 && (a.H % LN) == 0) return a.Hn / LN;
+    return 0;
 }
 
 int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
