@@ -365,11 +365,11 @@ __global__ __launch_bounds__(256) void choose_token_kernel(
 }
 
 // Output layer + token choice of one decode step in one launch (vae.py:455-464:
-// output_layer, search.step): a block takes 32 batch rows; its 4 waves share
+// output_layer, search.step): a block takes 16 batch rows; its 8 waves share
 // the (column tile, K part) items of logits = h . Wout^T on fp32 MFMA with
 // operands read straight from L2 (h was just written, Wout is 120 KB), the
-// partial tiles meet in LDS, and one thread per row scans its V logits with
-// the same arithmetic as choose_token_kernel.  Replaces a 35 us generic GEMM
+// partial tiles meet in LDS, and the row's V logits are searched with the
+// same result as choose_token_kernel (sampling: the same arithmetic).  Replaces a 35 us generic GEMM
 // + a 21 us one-thread-per-row scan (batch 4096) on the decode critical path.
 struct LogitsChooseArgs {
     const float *h;        // [B, ldh] top-layer hidden
@@ -384,58 +384,62 @@ struct LogitsChooseArgs {
     uint64_t seed;
 };
 constexpr int LC_MAX_ITEMS = 8;
-constexpr int LC_LD = 33;   // padded row of a 32 x 32 tile in LDS
+constexpr int LC_ROWS = 16;  // batch rows per block
+constexpr int LC_LD = 17;    // padded row of a 16 x 16 tile in LDS
 
-__global__ __launch_bounds__(256) void logits_choose_kernel(LogitsChooseArgs a) {
-    __shared__ float part[LC_MAX_ITEMS][32][LC_LD];
+// 16 rows per block (256 blocks at 4096 rows; 32-row blocks left half the CUs
+// idle and every wave with a chain of 128 dependent 32x32x2 MFMAs: 17.5 us per
+// step), 8 waves = (16-column tile, K part) items on 16x16x4 MFMAs, then 32
+// threads per row for the bias / arg-max (first maximum in vocabulary order).
+__global__ __launch_bounds__(512) void logits_choose_kernel(LogitsChooseArgs a) {
+    __shared__ float part[LC_MAX_ITEMS][LC_ROWS][LC_LD];
+    __shared__ float rowmax[LC_ROWS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lrow = lane & 31, lh = lane >> 5;
-    const int b0 = blockIdx.x * 32;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int b0 = blockIdx.x * LC_ROWS;
     const int items = a.NT * a.ksplit, klen = a.H / a.ksplit;
-    const float *hrow = a.h + (long long)min(b0 + lrow, a.B - 1) * a.ldh + 4 * lh;
-    for (int item = wave; item < items; item += 4) {
+    const float *hrow = a.h + (long long)min(b0 + r16, a.B - 1) * a.ldh + 4 * g;
+    for (int item = wave; item < items; item += 8) {
         const int tile = item % a.NT, kp = item / a.NT;
         const float *wrow =
-            a.w + (long long)min(tile * 32 + lrow, a.V - 1) * a.H + 4 * lh;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            a.w + (long long)min(tile * 16 + r16, a.V - 1) * a.H + 4 * g;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const int kend = (kp + 1) * klen;
         int k = kp * klen;
-        // 8 fragment pairs (64 of K) in flight per round, then the remainder
-        for (; k + 64 <= kend; k += 64) {
+        // 8 fragment pairs (128 of K) in flight per round, then the remainder
+        for (; k + 128 <= kend; k += 128) {
             f32x4 fa[8], fb[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                fa[i] = *(const f32x4 *)(hrow + k + 8 * i);
-                fb[i] = *(const f32x4 *)(wrow + k + 8 * i);
+                fa[i] = *(const f32x4 *)(hrow + k + 16 * i);
+                fb[i] = *(const f32x4a4 *)(wrow + k + 16 * i);
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[i][e],
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][e], fb[i][e],
                                                                acc, 0, 0, 0);
         }
-        for (; k < kend; k += 8) {
+        for (; k < kend; k += 16) {
             const f32x4 fa = *(const f32x4 *)(hrow + k);
-            const f32x4 fb = *(const f32x4 *)(wrow + k);
+            const f32x4 fb = *(const f32x4a4 *)(wrow + k);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0,
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], fb[e], acc, 0,
                                                            0, 0);
         }
+        // D[i][j]: lane holds rows i = 4 g + e, column j = r16
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            part[item][(r & 3) + 8 * (r >> 2) + 4 * lh][lrow] = acc[r];
+        for (int e = 0; e < 4; ++e) part[item][4 * g + e][r16] = acc[e];
     }
     __syncthreads();
     // final logits (K parts summed in order, bias last as the GEMM does) land
     // in the first K part's tiles
-    for (int idx = tid; idx < 32 * a.V; idx += 256) {
+    for (int idx = tid; idx < LC_ROWS * a.V; idx += 512) {
         const int r = idx / a.V, v = idx - r * a.V;
-        const int tile = v >> 5, c = v & 31;
+        const int tile = v >> 4, c = v & 15;
         float x = part[tile][r][c];
         for (int kp = 1; kp < a.ksplit; ++kp) x += part[kp * a.NT + tile][r][c];
         if (a.bias) x += a.bias[v];
@@ -444,43 +448,50 @@ __global__ __launch_bounds__(256) void logits_choose_kernel(LogitsChooseArgs a) 
             a.logits_out[(long long)(b0 + r) * a.V + v] = x;
     }
     __syncthreads();
-    __shared__ float rowmax[32];
-    const int b = b0 + tid;
-    auto lg = [&](int v) -> float & { return part[v >> 5][tid][v & 31]; };
-    int pick = 0;
-    if (tid < 32) {
-        float m = -INFINITY;
-        for (int v = 0; v < a.V; ++v) {
-            const float xv = lg(v);
-            if (xv > m) { m = xv; pick = v; }
-        }
-        rowmax[tid] = m;
+    auto lg = [&](int r, int v) -> float & { return part[v >> 4][r][v & 15]; };
+    // arg-max: 32 threads per row, each over v = sub, sub + 32, ...; ties go to
+    // the smaller index, as a scan in vocabulary order would leave them
+    const int row = tid >> 5, sub = tid & 31;
+    float m = -INFINITY;
+    int pick = 0x7fffffff;
+    for (int v = sub; v < a.V; v += 32) {
+        const float xv = lg(row, v);
+        if (xv > m) { m = xv; pick = v; }
     }
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) {
+        const float om = __shfl_xor(m, d);
+        const int op = __shfl_xor(pick, d);
+        if (om > m || (om == m && op < pick)) { m = om; pick = op; }
+    }
+    if (pick == 0x7fffffff) pick = 0;   // nothing compared greater (NaN row)
+    if (sub == 0) rowmax[row] = m;
+    const int b = b0 + row;
     if (a.search == PCM_SEARCH_SAMPLING) {
         // softmax(logits / T), inverse-CDF draw: the exponentials are taken by
         // all threads, the sums stay one thread's, in vocabulary order
         __syncthreads();
-        for (int idx = tid; idx < 32 * a.V; idx += 256) {
+        for (int idx = tid; idx < LC_ROWS * a.V; idx += 512) {
             const int r = idx / a.V, v = idx - r * a.V;
-            float &x = part[v >> 5][r][v & 31];
+            float &x = lg(r, v);
             x = expf((x - rowmax[r]) * a.inv_temp);
         }
         __syncthreads();
-        if (tid < 32) {
+        if (sub == 0) {
             float s = 0.f;
-            for (int v = 0; v < a.V; ++v) s += lg(v);
+            for (int v = 0; v < a.V; ++v) s += lg(row, v);
             const float u =
                 pcm_uniform(a.seed, ((uint64_t)(uint32_t)a.step << 32) |
                                         (uint32_t)b) * s;
             float c = 0.f;
             pick = a.V - 1;
             for (int v = 0; v < a.V; ++v) {
-                c += lg(v);
+                c += lg(row, v);
                 if (c > u) { pick = v; break; }
             }
         }
     }
-    if (tid >= 32 || b >= a.B) return;
+    if (sub != 0 || b >= a.B) return;
     a.next_tok[b] = pick;
     a.tokens_out[(long long)b * a.out_stride + a.out_col] = pick;
 }
@@ -512,18 +523,21 @@ int pcm_launch_logits_choose(const float *h, long long ldh, const float *w,
                              int64_t *next_tok, int64_t *tokens_out,
                              long long out_stride, int out_col,
                              float *logits_out, hipStream_t stream) {
-    const int NT = (V + 31) / 32;
-    if (NT > LC_MAX_ITEMS || (H % 32) != 0 || (ldh % 4) != 0) return 0;
+    const int NT = (V + 15) / 16;
+    if (NT > LC_MAX_ITEMS || (H % 16) != 0 || (ldh % 4) != 0 ||
+        ((uintptr_t)h & 15))
+        return 0;
     LogitsChooseArgs a;
     a.h = h; a.w = w; a.bias = bias; a.logits_out = logits_out;
     a.next_tok = next_tok; a.tokens_out = tokens_out;
     a.ldh = ldh; a.out_stride = out_stride;
     a.B = B; a.V = V; a.H = H; a.NT = NT;
-    a.ksplit = NT >= 4 ? 1 : 4 / NT;   // H % 32 == 0: every part is whole 8s
+    a.ksplit = NT >= 8 ? 1 : 8 / NT;
+    while (a.ksplit > 1 && (H % (16 * a.ksplit)) != 0) a.ksplit >>= 1;
     a.search = search; a.step = step; a.out_col = out_col;
     a.inv_temp = 1.0f / temperature; a.seed = seed;
-    hipLaunchKernelGGL(logits_choose_kernel, dim3((B + 31) / 32), dim3(256), 0,
-                       stream, a);
+    hipLaunchKernelGGL(logits_choose_kernel, dim3((B + LC_ROWS - 1) / LC_ROWS),
+                       dim3(512), 0, stream, a);
     return 1;
 }
 
