@@ -820,6 +820,25 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd64_kernel(CellFwdArgs a) {
         acc_r[r] = 0.f; acc_z[r] = 0.f; acc_ni[r] = 0.f; acc_nh[r] = 0.f;
     }
     const int rh = wave & 1, ch = wave >> 1;
+    if (a.tokg) {
+        // layer 0: the token's gate-table rows (the embedding side of the input
+        // product) are the accumulators' start values -- 48 gathers per lane in
+        // flight while the loaders fetch the first chunks, instead of 2 x 24
+        // between the epilogue's math and stores (4.5 us of a 68 us launch)
+        const int jt = j0 + 32 * ch + lrow;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int b = min(b0 + 32 * rh + (r & 3) + 8 * (r >> 2) + 4 * lh,
+                              a.B - 1);
+            long long tk = a.tok[b];
+            if (tk < 0 || tk >= a.V) {
+                tk = tk < 0 ? 0 : a.V - 1;
+                if (a.status) atomicOr(a.status, PCM_STATUS_BAD_TOKEN);
+            }
+            const float *tg = a.tokg + tk * (3LL * a.Hn) + jt;
+            acc_r[r] = tg[0]; acc_z[r] = tg[a.Hn]; acc_ni[r] = tg[2 * a.Hn];
+        }
+    }
     // k group q (8 wide) of a chunk = granules 4 q + lh + 2 s (s = 0, 1) of the
     // lane's activation row and of its weight row of every gate; every such
     // row r has ((r >> 1) & 7) == ((lrow >> 1) & 7)
@@ -887,6 +906,8 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd64_kernel(CellFwdArgs a) {
     constexpr int HT = 68;
     const bool ctrl = a.cs_part != nullptr;
     f32x4 wv[8];
+    CellFwdArgs an = a;    // (the token gates are in the sums already)
+    an.tokg = nullptr;
     // in groups of eight: all of a group's operand loads are requested before
     // its first store (an element at a time, every element's loads queue behind
     // the stores of the one before: 16 memory round trips per lane)
@@ -899,7 +920,7 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd64_kernel(CellFwdArgs a) {
             const int b = b0 + 32 * rh + (r & 3) + 8 * (r >> 2) + 4 * lh;
             const float s[4] = {acc_r[r], acc_z[r], acc_ni[r], acc_nh[r]};
             out[i].hn = 0.f;
-            if (b < a.B) out[i] = cell_fwd_math(a, b, j, s);
+            if (b < a.B) out[i] = cell_fwd_math(an, b, j, s);
         }
         if (ctrl && g8 == 1) {
             // (requested once the accumulators are dead: 32 registers)
