@@ -165,6 +165,12 @@ def train_vae(
         optimizer = OPTIMIZER_FACTORY[optimizer](vae_model.parameters(), lr=lr)
     t = time()
     loss = decoder_loss = None
+    # the per-step host read of training.py:154 (loss.item()), with the
+    # bad-token status of the whole model folded into the same read, is
+    # collected one step late: the next step is already queued on the GPU when
+    # the host blocks, so the device never waits for the DataLoader, the batch
+    # preparation or the launch of the next forward
+    pending = None
     for _iter, batch in enumerate(train_dataloader):
         global_step = epoch * len(train_dataloader) + _iter
         encoder_seq, decoder_seq, target_seq = data_preparation(
@@ -179,12 +185,15 @@ def train_vae(
             decoder_loss, mu, logvar, kl_growth=kl_growth, step=global_step
         )
         loss.backward()
-        # the per-step sync of training.py:154, with the bad-token status of
-        # the whole model folded into the same device->host read
-        train_loss += vae_model.loss_item(loss)
+        ticket = vae_model.loss_ticket(loss)
         optimizer.step()
+        if pending is not None:
+            train_loss += pending.result()
+        pending = ticket
 
         if _iter and _iter % log_interval == 0:
+            train_loss += pending.result()
+            pending = None
             logger.info(
                 f'***TRAINING***\t Epoch: {epoch}, '
                 f'step {_iter}/{len(train_dataloader)}.\t'
@@ -239,6 +248,8 @@ def train_vae(
                     )
             with open(os.path.join(model_dir, 'loss_tracker.json'), 'w') as fp:
                 json.dump(loss_tracker, fp)
+    if pending is not None:
+        pending.result()   # (a bad token in the last step raises here)
     if loss is not None:
         logger.info(
             f'Epoch {epoch} finished, \t Training Loss = {loss.item():.4f},'

@@ -279,6 +279,52 @@ class StackGRUDecoder(StackGRU):
             )
 
 
+class _LossTicket:
+    """Pending device->host read of (loss, status flags); see
+    ``TeacherVAE.loss_ticket``."""
+
+    def __init__(self, model, loss):
+        self._model = model
+        self._words = [
+            m._status for m in model._stackgrus() if m._status is not None
+        ]
+        self._event = None
+        if not self._words or not loss.is_cuda:
+            model.check_tokens()
+            self._pair = (loss.detach().item(), 0.0)
+            return
+        flags = self._words[0]
+        for other in self._words[1:]:
+            if other is not flags:
+                flags = flags | other
+        packed = torch.cat(
+            [loss.detach().reshape(1).double(), flags.double()]
+        )
+        self._host = torch.empty(2, dtype=torch.float64, pin_memory=True)
+        self._host.copy_(packed, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record()
+        self._pair = None
+
+    def result(self):
+        if self._pair is None:
+            self._event.synchronize()
+            self._pair = tuple(self._host.tolist())
+        value, status = self._pair
+        if int(status):
+            for word in self._words:
+                word.zero_()
+            self._pair = (value, 0.0)
+        if int(status) & _lib.STATUS_TIMEOUT:
+            raise _lib.PaccmannHipError(
+                'the persistent forward kernel gave up waiting for its peer '
+                'blocks; results are invalid (PCM_PERSIST=0 disables it)'
+            )
+        if int(status) & _lib.STATUS_BAD_TOKEN:
+            raise RuntimeError('index out of range in self (token ids)')
+        return value
+
+
 class TeacherVAE(nn.Module):
     """vae.py:492-681."""
 
@@ -348,28 +394,15 @@ class TeacherVAE(nn.Module):
         """``loss.item()`` and ``check_tokens()`` in ONE device->host read (the
         per-step sync point of training.py:154): returns the loss as a float,
         raises RuntimeError for out-of-vocabulary token ids."""
-        words = [m._status for m in self._stackgrus() if m._status is not None]
-        if not words or not loss.is_cuda:
-            self.check_tokens()
-            return loss.detach().item()
-        flags = words[0]
-        for other in words[1:]:
-            if other is not flags:
-                flags = flags | other
-        value, status = torch.cat(
-            [loss.detach().reshape(1).double(), flags.double()]
-        ).tolist()
-        if int(status):
-            for word in words:
-                word.zero_()
-        if int(status) & _lib.STATUS_TIMEOUT:
-            raise _lib.PaccmannHipError(
-                'the persistent forward kernel gave up waiting for its peer '
-                'blocks; results are invalid (PCM_PERSIST=0 disables it)'
-            )
-        if int(status) & _lib.STATUS_BAD_TOKEN:
-            raise RuntimeError('index out of range in self (token ids)')
-        return value
+        return self.loss_ticket(loss).result()
+
+    def loss_ticket(self, loss):
+        """The same read, asynchronous: the loss and the status words are
+        copied to pinned host memory in stream order now; ``result()`` waits
+        for that copy only.  ``train_vae`` collects a step's ticket after the
+        NEXT step has been enqueued, so the GPU never idles behind the host's
+        per-step read (a bad token then raises one step late)."""
+        return _LossTicket(self, loss)
 
     def generate(
         self, latent_z, prime_input, end_token, generate_len=100,
