@@ -743,13 +743,34 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(
             ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
 }
 
+// block: 64 columns x 4 part groups; group g sums its contiguous quarter of the
+// partials in order with 8 loads in flight (one thread per column walking all
+// 240 partials of a T*B = 61440-row reduction one dependent load at a time took
+// 55 us), then the groups are combined in order.
 __global__ __launch_bounds__(256) void colsum_final_kernel(
     const float *partial, int parts, int N, float *out, const float *alpha_ptr,
     int accumulate) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + col;
+    const int per = (parts + 3) >> 2;
+    const int k0 = grp * per, k1 = min(parts, k0 + per);
     float s = 0.0f;
-    for (int k = 0; k < parts; ++k) s += partial[(long long)k * N + n];
+    if (n < N) {
+        int k = k0;
+        for (; k + 8 <= k1; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = partial[(long long)(k + i) * N + n];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+        }
+        for (; k < k1; ++k) s += partial[(long long)k * N + n];
+    }
+    red[grp][col] = s;
+    __syncthreads();
+    if (grp != 0 || n >= N) return;
+    s = ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
     const float alpha = alpha_ptr ? *alpha_ptr : 1.0f;
     float v = alpha * s;
     if (accumulate) v += out[n];
@@ -772,7 +793,7 @@ int pcm_colsum_launch(const float *X, long long ldx, int M, int N, float *out,
     dim3 g1((N + 63) / 64, parts);
     hipLaunchKernelGGL(colsum_partial_kernel, g1, dim3(256), 0, stream, X, ldx,
                        M, N, (float *)scratch);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 63) / 64), dim3(256), 0,
                        stream, (const float *)scratch, parts, N, out, alpha_ptr,
                        accumulate);
     return pcm_check_launch("colsum");
