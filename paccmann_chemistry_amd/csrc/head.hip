@@ -368,8 +368,9 @@ __global__ __launch_bounds__(256) void choose_token_kernel(
 // output_layer, search.step): a block takes 16 batch rows; its 8 waves share
 // the (column tile, K part) items of logits = h . Wout^T on fp32 MFMA with
 // operands read straight from L2 (h was just written, Wout is 120 KB), the
-// partial tiles meet in LDS, and the row's V logits are searched with the
-// same result as choose_token_kernel (sampling: the same arithmetic).  Replaces a 35 us generic GEMM
+// partial tiles meet in LDS, and the row's V logits are searched by 32 threads
+// (greedy: the same token as choose_token_kernel; sampling: the same draw, the
+// cumulative sums associated per thread and then across threads).  Replaces a 35 us generic GEMM
 // + a 21 us one-thread-per-row scan (batch 4096) on the decode critical path.
 struct LogitsChooseArgs {
     const float *h;        // [B, ldh] top-layer hidden
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(512) void logits_choose_kernel(LogitsChooseArgs a) 
     const int b = b0 + row;
     if (a.search == PCM_SEARCH_SAMPLING) {
         // softmax(logits / T), inverse-CDF draw: the exponentials are taken by
-        // all threads, the sums stay one thread's, in vocabulary order
+        // all threads
         __syncthreads();
         for (int idx = tid; idx < LC_ROWS * a.V; idx += 512) {
             const int r = idx / a.V, v = idx - r * a.V;
@@ -477,19 +478,41 @@ __global__ __launch_bounds__(512) void logits_choose_kernel(LogitsChooseArgs a) 
             x = expf((x - rowmax[r]) * a.inv_temp);
         }
         __syncthreads();
-        if (sub == 0) {
-            float s = 0.f;
-            for (int v = 0; v < a.V; ++v) s += lg(row, v);
-            const float u =
-                pcm_uniform(a.seed, ((uint64_t)(uint32_t)a.step << 32) |
-                                        (uint32_t)b) * s;
-            float c = 0.f;
-            pick = a.V - 1;
-            for (int v = 0; v < a.V; ++v) {
-                c += lg(row, v);
-                if (c > u) { pick = v; break; }
-            }
+        // inverse CDF over the row's 32 threads: thread `sub` owns the nper
+        // consecutive entries from sub * nper on; local running sums, an
+        // exclusive scan of the thread totals, the first entry whose
+        // cumulative sum exceeds u * total (one thread per row walking the
+        // vocabulary twice took 9 of the launch's 19 us)
+        const int nper = (a.V + 31) >> 5;        // <= 4 (V <= 128)
+        float cum[4];
+        float run = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = sub * nper + i;
+            if (i < nper && v < a.V) run += lg(row, v);
+            cum[i] = run;
         }
+        float incl = run;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const float up = __shfl_up(incl, d, 32);
+            if (sub >= d) incl += up;
+        }
+        const float total = __shfl(incl, 31, 32);
+        float base = __shfl_up(incl, 1, 32);     // exclusive prefix
+        if (sub == 0) base = 0.f;
+        const float u =
+            pcm_uniform(a.seed, ((uint64_t)(uint32_t)a.step << 32) |
+                                    (uint32_t)b) * total;
+        pick = 0x7fffffff;
+#pragma unroll
+        for (int i = 3; i >= 0; --i) {
+            const int v = sub * nper + i;
+            if (i < nper && v < a.V && base + cum[i] > u) pick = v;
+        }
+#pragma unroll
+        for (int d = 16; d >= 1; d >>= 1) pick = min(pick, __shfl_xor(pick, d));
+        if (pick == 0x7fffffff) pick = a.V - 1;
     }
     if (sub != 0 || b >= a.B) return;
     a.next_tok[b] = pick;
