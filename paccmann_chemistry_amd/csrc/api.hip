@@ -232,7 +232,7 @@ int pcm_sg_layout(const pcm_dims *d, int steps, int training, int dropout,
     }
     o->off_sync = take(off, pcm_persist_fwd_sync_words());
     o->off_cspart =
-        take(off, o->use_stack ? (size_t)o->B * (o->Hn / 32) * 64 : 0);
+        take(off, o->use_stack ? (size_t)o->B * (o->Hn / 16) * 64 : 0);
     o->off_cpre = take(off, o->use_stack ? (size_t)steps * o->B * 64 : 0);
     o->off_tokg = take(off, (size_t)o->V * 3 * o->Hn);
     for (int l = 0; l < o->L; ++l) {
@@ -336,7 +336,7 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         s.B = Bt; s.H = lay.H; s.Hp = lay.Hp; s.D = lay.D; s.W = lay.W;
         s.Wp = lay.Wp; s.AVW = lay.AVW; s.t = t;
         s.cs_part = (cs_part && have_part && *have_part)
-                        ? cs_part + (size_t)b0 * (lay.Hn / 32) * 64 : nullptr;
+                        ? cs_part + (size_t)b0 * (lay.Hn / 16) * 64 : nullptr;
         s.cs_parts = have_part ? *have_part : 0;
         pcm_probe_begin(PCM_K_STACK_FWD);
         int rc = pcm_launch_stack_fwd(s, st);
@@ -365,7 +365,7 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         c.cs_ctrl_w = c.cs_push_w = nullptr; c.cs_part = nullptr; c.cs_W = 0;
         c.xt_part = nullptr; c.su_S = nullptr;
         if (fuse && l == 0) {
-            c.xt_part = cs_part + (size_t)b0 * (lay.Hn / 32) * 64;
+            c.xt_part = cs_part + (size_t)b0 * (lay.Hn / 16) * 64;
             c.xt_parts = lay.Hn / 32;
             c.xt_ctrl_b = w->ctrl_b; c.xt_push_b = w->push_b;
             c.xt_S = sb.S_prev + oS;
@@ -388,7 +388,7 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
                 // width; a chain's slice starts at the widest layout's offset
                 *have_part = pcm_cell_fwd_ctrl_partials(c);
                 c.cs_part = *have_part
-                                ? cs_part + (size_t)b0 * (lay.Hn / 32) * 64
+                                ? cs_part + (size_t)b0 * (lay.Hn / 16) * 64
                                 : nullptr;
             }
         }
@@ -1420,7 +1420,7 @@ static int gen_layout(const pcm_dims *dims, GenLayout *g) {
     g->off_logits = take(off, (size_t)lay.B * lay.V);
     g->off_tok = take(off, (size_t)lay.B * 2);  // int64[B]
     g->off_cspart =
-        take(off, lay.use_stack ? (size_t)lay.B * (lay.Hn / 32) * 64 : 0);
+        take(off, lay.use_stack ? (size_t)lay.B * (lay.Hn / 16) * 64 : 0);
     for (int l = 0; l < lay.L; ++l) {
         g->off_wpack[l] = take(off, (size_t)3 * lay.Hn * lay.Kp[l]);
         g->off_bpack[l] = take(off, (size_t)4 * lay.Hn);

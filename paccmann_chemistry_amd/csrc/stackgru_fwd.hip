@@ -590,6 +590,16 @@ __global__ __launch_bounds__(512) void gru_cell_fwd16_kernel(CellFwdArgs a) {
 
     f32x4v acc_r = {0.f, 0.f, 0.f, 0.f}, acc_z = acc_r, acc_ni = acc_r,
            acc_nh = acc_r;
+    // control partials (top layer with a stack, see cell_fwd_tail): wave w's
+    // weight fragment of output 16 (w >> 1) + r16, k = j0 + 4 g .. + 3
+    f32x4v wf = {0.f, 0.f, 0.f, 0.f};
+    if (a.cs_part) {
+        const int o = 16 * (wave >> 1) + (lane & 15);
+        if (o < 3 + a.cs_W)
+            wf = *(const f32x4a4 *)((o < 3 ? a.cs_ctrl_w + (long long)o * a.H
+                                           : a.cs_push_w + (long long)(o - 3) * a.H) +
+                                    j0 + 4 * (lane >> 4));
+    }
 
     if (wave >= 4) {
         // loaders: wave lw issues instructions 5 lw .. 5 lw + 4 of a chunk;
@@ -712,6 +722,11 @@ __global__ __launch_bounds__(512) void gru_cell_fwd16_kernel(CellFwdArgs a) {
         }
     }
     __syncthreads();
+    constexpr int HT = 20;                 // row stride of the hidden tile
+    float *tile = lds + 8 * 4 * 64;        // behind the reduction buffer
+    CellFwdOut out[2];
+    bool live[2] = {false, false};
+    int ob[2] = {0, 0};
     if (wave < 4) {
         const int r16 = lane & 15, g = lane >> 4;
         const int rh = wave & 1, kh = wave >> 1;
@@ -727,8 +742,41 @@ __global__ __launch_bounds__(512) void gru_cell_fwd16_kernel(CellFwdArgs a) {
                 s[tl] = kh == 0 ? mine[tl] + src[tl * 64]
                                 : src[tl * 64] + mine[tl];
             const int b = b0 + rh * 16 + 4 * g + e, j = j0 + r16;
-            if (b >= a.B || j >= a.H) continue;
-            cell_fwd_element(a, b, j, s);
+            ob[p] = b;
+            live[p] = b < a.B && j < a.H;
+            out[p].hn = 0.f;
+            if (live[p]) out[p] = cell_fwd_math(a, b, j, s);
+            if (a.cs_part) tile[(rh * 16 + 4 * g + e) * HT + r16] = out[p].hn;
+        }
+    }
+    f32x4v part = {0.f, 0.f, 0.f, 0.f};
+    if (a.cs_part) {
+        // [32 rows x 16 k] . [16 k x 64 outputs] as eight 16 x 16 tiles, one per
+        // wave (row half w & 1, output tile w >> 1), before the global stores
+        __syncthreads();
+        const int r16 = lane & 15, g = lane >> 4;
+        const f32x4v fa =
+            *(const f32x4v *)(tile + (16 * (wave & 1) + r16) * HT + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            part = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[e], wf[e], part, 0, 0,
+                                                        0);
+    }
+    if (wave < 4) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            if (live[p]) cell_fwd_store(a, ob[p], j0 + (lane & 15), out[p]);
+    }
+    if (a.cs_part) {
+        // D[i][j]: lane (r16, g) holds rows i = 4 g + e of the half, column r16
+        const int r16 = lane & 15, g = lane >> 4;
+        const int parts = a.Hn / NCN;
+        float *dst = a.cs_part + ((long long)b0 * parts + blockIdx.x) * 64 +
+                     16 * (wave >> 1) + r16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = 16 * (wave & 1) + 4 * g + e;
+            if (b0 + row < a.B) dst[(long long)row * parts * 64] = part[e];
         }
     }
 }
@@ -1044,8 +1092,20 @@ __global__ __launch_bounds__(STHREADS, LEAN ? 4 : 2) void stack_step_fwd_kernel(
         for (int r = 0; r < SROWS; ++r) {
             const int b = min(b0 + r, a.B - 1);
             const float *src = a.cs_part + (long long)b * a.cs_parts * 64 + o;
+            // (loads of a group in flight together, added in order)
             float v = 0.f;
-            for (int p = p0; p < p1; ++p) v += src[p * 64];
+            int p = p0;
+            for (; p + 4 <= p1; p += 4) {
+                const float t0 = src[p * 64], t1 = src[(p + 1) * 64];
+                const float t2 = src[(p + 2) * 64], t3 = src[(p + 3) * 64];
+                v += t0; v += t1; v += t2; v += t3;
+            }
+            if (p + 2 <= p1) {
+                const float t0 = src[p * 64], t1 = src[(p + 1) * 64];
+                v += t0; v += t1;
+                p += 2;
+            }
+            if (p < p1) v += src[p * 64];
             hrow[(r * 8 + g) * 64 + o] = v;
         }
     }
@@ -1652,12 +1712,13 @@ static int cell_fwd_tile(const CellFwdArgs &a) {
 int pcm_cell_fwd_tile(const CellFwdArgs &a) { return cell_fwd_tile(a); }
 
 int pcm_cell_fwd_ctrl_partials(const CellFwdArgs &a) {
-    // the 32 x 32 and the 64 x 64 kernels' tails compute them: one partial per
-    // column tile (0: this launch writes none)
+    // every forward tile's tail computes them: one partial per column tile (0:
+    // this launch writes none)
     if (!a.cs_part || a.H != a.Hn || 3 + a.cs_W > 64) return 0;
     const int tile = cell_fwd_tile(a);
     if (tile == 32 && (a.H % CN) == 0) return a.Hn / CN;
     if (tile == 64 && (a.H % LN) == 0) return a.Hn / LN;
+    if (tile == 16 && (a.H % NCN) == 0) return a.Hn / NCN;
     return 0;
 }
 
@@ -1666,6 +1727,9 @@ int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
     const int tile = cell_fwd_tile(a);
     PCM_REQUIRE(tile == 32 || (!a.su_S && !a.xt_part), PCM_EINVAL,
                 "cell_fwd: the fused stack step needs the 32 x 32 tile");
+    PCM_REQUIRE(!a.cs_part || pcm_cell_fwd_ctrl_partials(a) > 0, PCM_EINVAL,
+                "cell_fwd: control partials asked of a launch that cannot "
+                "write them (tile %d, H %d, Hn %d)", tile, a.H, a.Hn);
     if (tile == 64) {
         dim3 grid(a.Hn / LN, (a.B + LM - 1) / LM);
         if (g_pcm_matmul_bf16)
