@@ -168,6 +168,76 @@ def test_packed_training_step_matches_oracle():
     assert not bad, bad
 
 
+def test_example_params_shape_matches_oracle():
+    """The reference's examples/example_params.json model (vocabulary 380
+    one-hot, H=512, L=2, stack 50x50, latent 256, packed mode) at batch 64 x
+    T=40: the 380-wide vocabulary takes the paths the 60-token benchmark model
+    does not -- output layer and cross entropy as two launches (V > 128), the
+    token-table gradient as a product of its own (V > 64), the generic output
+    layer + search step in decoding.  Loss, mu, every gradient and 30 greedy
+    tokens against the oracle."""
+    from paccmann_chemistry_amd import GreedySearch, vae_loss_function
+    batch, steps = 64, 40
+    p = dict(CONFIG, batch_size=batch, batch_mode='packed', vocab_size=380,
+             embedding_size=380)
+    sd = W.make_state_dict(p, 4500)
+    tokens = W.synthetic_tokens(steps, batch, 380, 4501)
+    targets = W.shifted_targets(tokens)
+    rng = np.random.default_rng(4502)
+    lens = np.sort(rng.integers(5, steps + 1, size=batch))[::-1].copy()
+    lens[0] = steps
+    lengths = torch.from_numpy(lens.astype(np.int64))
+    eps = torch.from_numpy(np.random.default_rng(4503).standard_normal(
+        (batch, p['latent_dim'])).astype(np.float32))
+    vae = _build_vae(p, sd)
+    dev = _dev()
+    pack = torch.nn.utils.rnn.pack_sequence
+
+    def packed(x):
+        return pack([x[:n, b] for b, n in enumerate(lens.tolist())]).to(dev)
+
+    dec_loss, mu, logvar = vae(packed(tokens), packed(tokens), packed(targets),
+                               eps=eps.to(dev))
+    total, _ = vae_loss_function(dec_loss, mu, logvar, kl_growth=0.003,
+                                 step=5000)
+    total.backward()
+    vae.check_tokens()
+
+    ref = {k: v.clone().requires_grad_('embedding' not in k)
+           for k, v in sd.items()}
+    r_mu, r_logvar = O.encoder_forward(
+        O.sub_params(ref, 'encoder'), tokens, p['stack_depth'], lengths)
+    z = O.reparameterize(r_mu, r_logvar, eps)
+    r_loss, r_logits, _ = O.decoder_forward(
+        O.sub_params(ref, 'decoder'), z, tokens, targets, p['stack_depth'],
+        lengths)
+    r_total, _ = O.vae_loss(r_loss, r_mu, r_logvar, 0.003, step=5000)
+    r_total.backward()
+    assert _rel_to_max(mu, r_mu) < 1e-5
+    assert abs(total.item() - r_total.item()) < 1e-5 * abs(r_total.item())
+    bad = {}
+    for name, param in vae.named_parameters():
+        if ref[name].grad is None:
+            continue
+        err = _rel_to_max(param.grad, ref[name].grad)
+        if not err < GRAD_TOL:
+            bad[name] = err
+    assert not bad, bad
+
+    vae.eval()
+    zg = torch.from_numpy(np.random.default_rng(4504).standard_normal(
+        (batch, p['latent_dim'])).astype(np.float32))
+    prime, gen_len = torch.tensor([2]), 30
+    with torch.no_grad():
+        toks, logits = vae.decoder.generate_from_latent(
+            zg.unsqueeze(0).to(dev), prime.to(dev), torch.tensor([3]),
+            search=GreedySearch(), generate_len=gen_len, return_logits=True)
+        r_toks, r_logits = O.generate_from_latent(
+            O.sub_params(sd, 'decoder'), zg, prime, gen_len, p['stack_depth'])
+    assert _rel_to_max(logits, r_logits) < LOGIT_TOL
+    assert torch.equal(toks.cpu(), r_toks)
+
+
 def test_sampling_tokens_bit_exact_against_oracle_distribution():
     """SamplingSearch.step at the config model (V=60, H=512), B=70: the device
     draw is a counter hash of (seed, step, row); with the same uniforms the
