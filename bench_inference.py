@@ -21,13 +21,21 @@ if ROOT not in sys.path:
 import bench  # noqa: E402  (model configuration of the headline benchmark)
 
 
+STREAMS = []   # --streams N > 1: independent batches alternate over N HIP streams
+
+
 def timed(fn, batches, warmup=2):
-    for _ in range(warmup):
-        fn()
+    def call(i):
+        if not STREAMS:
+            return fn()
+        with torch.cuda.stream(STREAMS[i % len(STREAMS)]):
+            return fn()
+    for i in range(max(warmup, 2 * len(STREAMS))):
+        call(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(batches):
-        fn()
+    for i in range(batches):
+        call(i)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / batches
 
@@ -37,6 +45,11 @@ def main():
     ap.add_argument('--batch', type=int, default=4096)
     ap.add_argument('--batches', type=int, default=10)
     ap.add_argument('--generate-len', type=int, default=100)
+    ap.add_argument('--streams', type=int, default=1,
+                    help='> 1: consecutive (independent) batches are enqueued '
+                         'on that many HIP streams in turn, one model; a '
+                         "chain's kernel boundaries and prologue / epilogue "
+                         "phases then run under another batch's MFMA loops")
     args = ap.parse_args()
     import paccmann_chemistry_amd as P
     from paccmann_chemistry_amd import synthetic as W
@@ -48,7 +61,12 @@ def main():
     vae.eval()
     seq_len, batch = bench.SEQ_LEN, args.batch
     common = {'n_gpus': 1, 'dtype': 'f32', 'data': 'synthetic',
-              'higher_is_better': True, 'batches': args.batches}
+              'higher_is_better': True, 'batches': args.batches,
+              'streams': args.streams}
+    if args.streams > 1:
+        STREAMS.extend(torch.cuda.Stream() for _ in range(args.streams))
+        args.batches = max(args.batches, 4 * args.streams)
+        common['batches'] = args.batches
 
     # ---- encoder only, fixed length (padded) and ragged (packed) ----------
     tokens = W.synthetic_tokens(seq_len, batch, p['vocab_size'], 1234).to(dev)

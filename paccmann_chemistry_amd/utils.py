@@ -263,7 +263,11 @@ def _unpack_sorted(packed):
     sizes = packed.batch_sizes
     steps, batch = int(sizes.numel()), int(sizes[0])
     device = packed.data.device
-    key = (device.type, device.index)
+    # (per stream: the cached index is filled by a copy in stream order, and a
+    # model may serve independent batches on several streams)
+    stream = torch.cuda.current_stream(device).cuda_stream \
+        if device.type == 'cuda' else 0
+    key = (device.type, device.index, stream)
     cached = _UNPACK_CACHE.get(key)
     if cached is None or not torch.equal(cached[0], sizes):
         offsets = torch.cumsum(sizes, 0) - sizes

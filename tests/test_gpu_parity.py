@@ -243,6 +243,63 @@ def test_greedy_decode_golden(name):
     assert np.array_equal(tokens.cpu().numpy(), g.data['tokens'])
 
 
+def test_one_model_serves_independent_batches_on_several_streams():
+    """bench_inference.py --streams N: consecutive, independent batches are
+    enqueued on N HIP streams in turn with ONE model (workspaces are allocated
+    per call in stream order, cached tables are per stream).  Encoder mu /
+    logvar (padded and packed) and greedy tokens of three different batches
+    over three streams equal the same calls one after the other, bit for
+    bit."""
+    import paccmann_chemistry_amd as P
+    from oracle import weights as W
+    p = {
+        'latent_dim': 16, 'rnn_cell_size': 64, 'embedding_size': 20,
+        'vocab_size': 20, 'stack_width': 6, 'stack_depth': 5, 'n_layers': 2,
+        'dropout': 0.0, 'batch_size': 48, 'batch_mode': 'padded',
+        'embedding': 'one_hot', 'use_stack': True, 'bidirectional': False
+    }
+    sd = W.make_state_dict(p, 5100)
+    vae = _build_vae(p, sd, train=False)
+    vae_packed = _build_vae(dict(p, batch_mode='packed'), sd, train=False)
+    dev = _dev()
+    steps, batch = 17, 48
+    pack = torch.nn.utils.rnn.pack_sequence
+    jobs = []
+    for k in range(3):
+        tokens = W.synthetic_tokens(steps, batch, 20, 5101 + k)
+        lens = sorted(np.random.default_rng(5110 + k).integers(
+            2, steps + 1, size=batch).tolist(), reverse=True)
+        packed = pack([tokens[:n, b] for b, n in enumerate(lens)]).to(dev)
+        z = torch.from_numpy(np.random.default_rng(5120 + k).standard_normal(
+            (1, batch, 16)).astype(np.float32)).to(dev)
+        jobs.append((tokens.to(dev), packed, z))
+    prime = torch.tensor([2], device=dev)
+    end = torch.tensor([3], device=dev)
+
+    def work(job):
+        tokens, packed, z = job
+        mu, logvar = vae.encode(tokens)
+        mu_p, logvar_p = vae_packed.encode(packed)
+        toks = vae.decoder.generate_from_latent(
+            z, prime, end, search=P.GreedySearch(), generate_len=12)
+        return mu, logvar, mu_p, logvar_p, toks
+
+    with torch.no_grad():
+        serial = [work(job) for job in jobs]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        for _ in range(2):   # second round: cached tables in use
+            outs = []
+            for k, job in enumerate(jobs):
+                with torch.cuda.stream(streams[k]):
+                    outs.append(work(job))
+            torch.cuda.synchronize()
+            for got, want in zip(outs, serial):
+                for a, b in zip(got, want):
+                    assert torch.equal(a, b)
+    vae.check_tokens()
+
+
 def test_determinism_bitwise():
     """Same inputs twice => bitwise identical loss and gradients."""
     g = Golden('vae_odd_padded')
