@@ -21,21 +21,27 @@ if ROOT not in sys.path:
 import bench  # noqa: E402  (model configuration of the headline benchmark)
 
 
-STREAMS = []   # --streams N > 1: independent batches alternate over N HIP streams
+STREAMS = 1   # --streams N > 1: N independent batches in flight (inference.py)
 
 
-def timed(fn, batches, warmup=2):
-    def call(i):
-        if not STREAMS:
-            return fn()
-        with torch.cuda.stream(STREAMS[i % len(STREAMS)]):
-            return fn()
-    for i in range(max(warmup, 2 * len(STREAMS))):
-        call(i)
+def timed(fn, batches, warmup=2, pipe=None):
+    """Seconds per batch: fn() once per batch, or -- with --streams N > 1 --
+    pipe(n), the product's pipelined loop over n batches."""
+    if STREAMS > 1 and pipe is not None:
+        for _ in pipe(max(warmup, 2 * STREAMS)):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in pipe(batches):
+            pass
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / batches
+    for _ in range(warmup):
+        fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(batches):
-        call(i)
+    for _ in range(batches):
+        fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / batches
 
@@ -46,10 +52,12 @@ def main():
     ap.add_argument('--batches', type=int, default=10)
     ap.add_argument('--generate-len', type=int, default=100)
     ap.add_argument('--streams', type=int, default=1,
-                    help='> 1: consecutive (independent) batches are enqueued '
-                         'on that many HIP streams in turn, one model; a '
-                         "chain's kernel boundaries and prologue / epilogue "
-                         "phases then run under another batch's MFMA loops")
+                    help='> 1: that many independent batches in flight on '
+                         'separate HIP streams (paccmann_chemistry_amd.'
+                         'inference.encode_batches / generate_batches), one '
+                         "model; a chain's kernel boundaries and prologue / "
+                         "epilogue phases then run under another batch's MFMA "
+                         'loops')
     args = ap.parse_args()
     import paccmann_chemistry_amd as P
     from paccmann_chemistry_amd import synthetic as W
@@ -64,14 +72,17 @@ def main():
               'higher_is_better': True, 'batches': args.batches,
               'streams': args.streams}
     if args.streams > 1:
-        STREAMS.extend(torch.cuda.Stream() for _ in range(args.streams))
+        global STREAMS
+        STREAMS = args.streams
         args.batches = max(args.batches, 4 * args.streams)
         common['batches'] = args.batches
 
     # ---- encoder only, fixed length (padded) and ragged (packed) ----------
     tokens = W.synthetic_tokens(seq_len, batch, p['vocab_size'], 1234).to(dev)
     with torch.no_grad():
-        sec = timed(lambda: vae.encode(tokens), args.batches)
+        sec = timed(lambda: vae.encode(tokens), args.batches,
+                    pipe=lambda n: P.encode_batches(vae, [tokens] * n,
+                                                    streams=args.streams))
     print(json.dumps(dict(
         common, metric='encoder-only molecules/sec (mu/logvar)',
         value=batch / sec, unit='molecules/s', ms_per_batch=sec * 1e3,
@@ -90,7 +101,9 @@ def main():
     vae_packed = P.TeacherVAE(P.StackGRUEncoder(q), P.StackGRUDecoder(q)).to(dev)
     vae_packed.eval()
     with torch.no_grad():
-        sec = timed(lambda: vae_packed.encode(packed), args.batches)
+        sec = timed(lambda: vae_packed.encode(packed), args.batches,
+                    pipe=lambda n: P.encode_batches(vae_packed, [packed] * n,
+                                                    streams=args.streams))
     print(json.dumps(dict(
         common, metric='encoder-only molecules/sec (mu/logvar)',
         value=batch / sec, unit='molecules/s', ms_per_batch=sec * 1e3,
@@ -110,7 +123,11 @@ def main():
             return vae.decoder.generate_from_latent(
                 z, prime, end, search=search,
                 generate_len=args.generate_len, seed=99)
-        sec = timed(run, args.batches, warmup=3)
+        sec = timed(run, args.batches, warmup=3,
+                    pipe=lambda n: P.generate_batches(
+                        vae, [z] * n, prime, end,
+                        generate_len=args.generate_len, search=search,
+                        streams=args.streams, seed=99))
         print(json.dumps(dict(
             common, metric=f'decode molecules/sec ({name})',
             value=batch / sec, unit='molecules/s', ms_per_batch=sec * 1e3,

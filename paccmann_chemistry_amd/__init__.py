@@ -15,5 +15,6 @@ from .vae import StackGRUDecoder, StackGRUEncoder, TeacherVAE  # noqa: F401
 from .loss_functions import vae_loss_function  # noqa: F401
 from .search import BeamSearch, GreedySearch, SamplingSearch  # noqa: F401
 from .ops import get_matmul_precision, set_matmul_precision  # noqa: F401
+from .inference import encode_batches, generate_batches  # noqa: F401
 
 __version__ = '0.1.0'

@@ -299,6 +299,22 @@ def test_one_model_serves_independent_batches_on_several_streams():
                     assert torch.equal(a, b)
     vae.check_tokens()
 
+    # the product's pipelined loops (inference.py) over the same batches
+    with torch.no_grad():
+        enc = list(P.encode_batches(vae, [j[0] for j in jobs], streams=3))
+        enc_p = list(P.encode_batches(vae_packed, [j[1] for j in jobs],
+                                      streams=2))
+        gen = list(P.generate_batches(vae, [j[2] for j in jobs], prime, end,
+                                      generate_len=12,
+                                      search=P.GreedySearch(), streams=3))
+    torch.cuda.synchronize()
+    for k, want in enumerate(serial):
+        assert torch.equal(enc[k][0], want[0])
+        assert torch.equal(enc[k][1], want[1])
+        assert torch.equal(enc_p[k][0], want[2])
+        assert torch.equal(enc_p[k][1], want[3])
+        assert torch.equal(gen[k], want[4])
+
 
 def test_determinism_bitwise():
     """Same inputs twice => bitwise identical loss and gradients."""
