@@ -67,13 +67,76 @@ def parse():
                          '"bf16": bf16-rounded MFMA operands in the cells and '
                          'the recurrent weight gradients, fp32 accumulation, '
                          'state and optimizer')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help='N > 1: weak = --batch sequences on EVERY GPU (global '
+                         'batch N x batch); strong = BASELINE.json config 3: '
+                         'the global batch --global-batch (4096) split over '
+                         'the N GPUs')
+    ap.add_argument('--global-batch', type=int, default=4096,
+                    help='global batch of --scaling strong')
+    ap.add_argument('--inference', type=int, default=1,
+                    help='1: after the training measurement also time the '
+                         'encoder-only and decode workloads (configs 4, 5) and '
+                         'the ragged packed training step; 0: off')
     ap.add_argument('--probe', type=int, default=1,
                     help='1: per-kernel launch durations from extra untimed '
                          'steps after the timed region (roofline); 0: off')
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error('--gpus must be >= 1')
+    if args.scaling == 'strong':
+        if args.global_batch % args.gpus:
+            ap.error('--global-batch must be a multiple of --gpus')
+        args.batch = args.global_batch // args.gpus
     if args.ragged:
         args.probe = 0   # per-launch FLOPs vary with the active row count
     return args
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the
+    environment: start the N ranks ourselves, exactly as the driver would
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...`), from
+    a parent that has touched no GPU; relay the children's output (rank 0's
+    JSON line) and exit with their status."""
+    import socket
+    import subprocess
+    port = os.environ.get('MASTER_PORT')
+    if port is None:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = str(s.getsockname()[1])
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+        'HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, world, rank):
+    """PCM_BENCH_DRYRUN=1 (tests/test_host_cpu.py): the launcher, rendezvous,
+    barrier and MAX-over-ranks legs of this file on the CPU (gloo), no GPU and
+    no library call; rank 0 prints a line that says so."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('gloo')
+    seen = torch.ones(1, dtype=torch.int64)
+    elapsed = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(seen)
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({
+            'dry_run': True, 'n_gpus': world, 'ranks_seen': int(seen.item()),
+            'scaling': args.scaling if world > 1 else 'weak',
+            'batch_per_gpu': args.batch,
+            'global_batch': world * args.batch,
+            'max_elapsed': float(elapsed.item())}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md, HBM3E
@@ -169,9 +232,17 @@ def cpu_baseline(p, cpu_batch):
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch '
+                 f'one rank per GPU (or run `python bench.py --gpus N`, which '
+                 f'starts them)')
+    if os.environ.get('PCM_BENCH_DRYRUN') == '1':
+        return dry_run(args, world, rank)
     import torch.distributed as dist
     # PCM_BENCH_FORCE_DIST=1 runs the N > 1 code path (process group, hook-driven
     # async all-reduce, barriers, MAX over ranks) in a one-rank RCCL group: the
@@ -369,7 +440,8 @@ def main():
             'value': value, 'unit': 'tokens/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak',
+            'higher_is_better': True,
+            'scaling': args.scaling if world > 1 else 'weak',
             'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32',
             'data': 'synthetic',
             'config': {

@@ -76,7 +76,11 @@ typedef struct pcm_stackgru_params {
 int pcm_version(void);
 /* Message of the last failing call on this thread ("" if none). */
 const char *pcm_last_error(void);
-/* 0 if a gfx950 device is current and usable, PCM_EDEVICE otherwise. */
+/* 0 if a gfx950 device is current and usable, PCM_EDEVICE otherwise.  Also the
+ * library's per-device set-up call: it resolves, for the current device, the
+ * address of the static scratch array pcm_softmax_ce_static uses (a symbol
+ * lookup that must not be issued inside a stream capture).  Call it once per
+ * device, with that device current, before capturing a graph. */
 int pcm_device_check(void);
 
 /*
@@ -291,6 +295,10 @@ int pcm_output_ce(const float *x, int64_t ldx, const float *w,
  * (PCM_EINVAL beyond it).  Every call on one GPU shares that GPU's array:
  * calls that overlap in time on one GPU (different streams / threads) race;
  * calls ordered on one stream are safe, nothing needs clearing in between.
+ * The array's device address is looked up once per device, by pcm_device_check()
+ * or else by the first call on that device: a caller that records this call
+ * into a HIP graph runs pcm_device_check() (or one eager call) on the device
+ * first, so that no symbol lookup happens under capture.
  */
 #define PCM_CE_STATIC_MAX_FLOATS (1 << 20) /* 4 MiB per GPU */
 int pcm_softmax_ce_static(const float *logits, const int64_t *targets,

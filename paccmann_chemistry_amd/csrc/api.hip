@@ -18,6 +18,7 @@ int pcm_launch_logits_choose(const float *h, long long ldh, const float *w,
                              int64_t *next_tok, int64_t *tokens_out,
                              long long out_stride, int out_col,
                              float *logits_out, hipStream_t stream);
+int pcm_ce_static_prepare(void);   // head.hip
 int pcm_launch_broadcast_token(const int64_t *src, int B, int64_t *next_tok,
                                int64_t *tokens_out, long long out_stride,
                                int out_col, hipStream_t stream);
@@ -212,6 +213,10 @@ int pcm_sg_layout(const pcm_dims *d, int steps, int training, int dropout,
     o->DW = o->D * o->W;
     size_t off = 0;
     const size_t BH = (size_t)o->B * o->Hp;
+    // the per-step hand-off regions of the persistent forward kernel exist only
+    // where that kernel can run (an eval-mode forward of the launch chain at
+    // batch 4096 x 120 steps would otherwise carry 250 MB it never touches)
+    const bool persist = o->use_stack && pcm_persist_fwd_supported(*o, nullptr);
     for (int l = 0; l < o->L; ++l) {
         o->Kx[l] = l == 0 ? o->W : o->H;
         o->Kxp[l] = l == 0 ? o->Wp : o->Hp;
@@ -228,12 +233,14 @@ int pcm_sg_layout(const pcm_dims *d, int steps, int training, int dropout,
         const size_t per = o->training ? steps : 1;
         o->off_S = take(off, slots * o->B * o->DW);
         o->off_av = take(off, per * o->B * o->AVW);
-        o->off_xtop = take(off, (size_t)steps * o->B * o->Wp);
+        o->xtop_per_step = (o->training || persist) ? 1 : 0;
+        o->off_xtop =
+            take(off, (size_t)(o->xtop_per_step ? steps : 1) * o->B * o->Wp);
     }
-    o->off_sync = take(off, pcm_persist_fwd_sync_words());
+    o->off_sync = take(off, persist ? pcm_persist_fwd_sync_words() : 0);
     o->off_cspart =
         take(off, o->use_stack ? (size_t)o->B * (o->Hn / 16) * 64 : 0);
-    o->off_cpre = take(off, o->use_stack ? (size_t)steps * o->B * 64 : 0);
+    o->off_cpre = take(off, persist ? (size_t)steps * o->B * 64 : 0);
     o->off_tokg = take(off, (size_t)o->V * 3 * o->Hn);
     for (int l = 0; l < o->L; ++l) {
         o->off_wpack[l] = take(off, (size_t)3 * o->Hn * o->Kp[l]);
@@ -574,7 +581,9 @@ int pcm_device_check(void) {
     PCM_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, PCM_EDEVICE,
                 "device %d is %s; this library is built for gfx950 only", dev,
                 prop.gcnArchName);
-    return PCM_OK;
+    // per-device set-up that must not happen inside a stream capture: the
+    // address of pcm_softmax_ce_static's scratch array on this device
+    return pcm_ce_static_prepare();
 }
 
 size_t pcm_stackgru_saved_bytes(const pcm_dims *dims, int32_t steps,
@@ -1137,22 +1146,25 @@ int pcm_stackgru_backward(const pcm_dims *dims,
         }
         return PCM_OK;
     };
-    // hand steps [t_lo, pending_hi) to the gradient stream
-    auto flush_param_grads = [&](int t_lo) -> int {
-        if (t_lo >= pending_hi) return PCM_OK;
-        if (side) stream_wait(side, st, gst);
-        int r = param_grads(t_lo, pending_hi, first_chunk, t_lo == 0);
-        first_chunk = false;
-        pending_hi = t_lo;
-        return r;
-    };
-
     // one chain over the whole batch, or two half-batch chains on two streams
     // (see chain_stream); everything below the loop runs on `st` after the join
     int split = fused_bwd ? chain_split(lay) : 0;
     SideStream *cs = split ? chain_stream() : nullptr;
     if (!cs) split = 0;
     const int nch = split ? 2 : 1;
+    // hand steps [t_lo, pending_hi) to the gradient stream
+    auto flush_param_grads = [&](int t_lo) -> int {
+        if (t_lo >= pending_hi) return PCM_OK;
+        if (side) stream_wait(side, st, gst);
+        // the second chain's rows of these steps are operands too (gst is the
+        // caller's stream when there is no side stream)
+        if (split) stream_wait(cs, cs->stream, gst);
+        int r = param_grads(t_lo, pending_hi, first_chunk, t_lo == 0);
+        first_chunk = false;
+        pending_hi = t_lo;
+        return r;
+    };
+
     if (split) stream_wait(cs, st, cs->stream);   // fork
     auto total_rows = [&](int t) { return active_rows ? active_rows[t] : B; };
     int cur_c[2] = {cur, cur};

@@ -790,6 +790,13 @@ static int ce_static_scratch(float **out) {
     return PCM_OK;
 }
 
+// called by pcm_device_check(): resolve the current device's address eagerly,
+// outside any stream capture
+int pcm_ce_static_prepare(void) {
+    float *unused = nullptr;
+    return ce_static_scratch(&unused);
+}
+
 extern "C" {
 
 int pcm_softmax_ce(const float *logits, const int64_t *targets,

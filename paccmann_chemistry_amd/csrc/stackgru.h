@@ -10,6 +10,7 @@
 struct SGLayout {
     int B, V, E, H, L, D, W, use_stack;
     int T, training, dropout;
+    int xtop_per_step;
     int Hp, Hn, Wp, AVW, DW;
     int Kx[PCM_MAX_LAYERS];   // width of the non-token GRU input of layer l
     int Kxp[PCM_MAX_LAYERS];  // ... padded to 64
@@ -19,13 +20,15 @@ struct SGLayout {
     size_t off_gates[PCM_MAX_LAYERS];  // T x B x 4H : r, z, n, W_hn.h+b_hn
     size_t off_S;      // training: (T+1) x B x D*W ; else 2 x B x D*W
     size_t off_av;     // training: T x B x AVW ; else B x AVW  (a[3], v[W])
-    size_t off_xtop;   // T x B x Wp (a slot per step in both modes: the
-                       // persistent kernel hands it over at fresh addresses)
+    size_t off_xtop;   // T x B x Wp when xtop_per_step (training, or the
+                       // persistent kernel, which hands it over at fresh
+                       // addresses), else one B x Wp slot
     size_t off_sync;   // hand-off counters of the persistent kernel (words)
     size_t off_cspart; // B x (Hn / 32) x 64: partial control / push sums that
                        // the top layer's forward cell leaves for the next stack step
     size_t off_cpre;   // T x B x 64: stack control / push pre-activations the
-                       // persistent kernel hands over (0 floats without a stack)
+                       // persistent kernel hands over (0 floats when that
+                       // kernel cannot take this shape)
     size_t off_tokg;   // V x 3*Hn   token gate table (b_ih0 folded in)
     size_t off_wpack[PCM_MAX_LAYERS];  // 3*Hn x Kp[l]
     size_t off_bpack[PCM_MAX_LAYERS];  // 4*Hn
@@ -38,7 +41,9 @@ struct SGLayout {
     size_t av_index(int t) const {
         return off_av + (size_t)(training ? t : 0) * B * AVW;
     }
-    size_t xtop_index(int t) const { return off_xtop + (size_t)t * B * Wp; }
+    size_t xtop_index(int t) const {
+        return off_xtop + (size_t)(xtop_per_step ? t : 0) * B * Wp;
+    }
 };
 
 int pcm_sg_layout(const pcm_dims *dims, int steps, int training, int dropout,

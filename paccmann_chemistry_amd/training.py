@@ -209,6 +209,17 @@ def train_vae(
             logger.info(
                 f'Sample input:\n\t {target}, model reconstructed:\n\t {pred}'
             )
+        saves = _iter and _iter % save_interval == 0
+        evaluates = _iter and _iter % eval_interval == 0
+        if (saves or evaluates) and pending is not None:
+            # a checkpoint (or an evaluation that may write best_*.pt) must not
+            # be written from weights that a step with clamped, out-of-range
+            # token ids has updated: collect this step's status first.  The
+            # reference raises inside the embedding lookup, before the update
+            # (stack_rnn.py:150); here the step that raises has already been
+            # applied to the in-memory model, but nothing is saved from it.
+            train_loss += pending.result()
+            pending = None
         if _iter and _iter % save_interval == 0:
             save_dir = os.path.join(
                 model_dir, f'weights/saved_model_epoch_{epoch}_iter_{_iter}.pt'
@@ -249,7 +260,8 @@ def train_vae(
             with open(os.path.join(model_dir, 'loss_tracker.json'), 'w') as fp:
                 json.dump(loss_tracker, fp)
     if pending is not None:
-        pending.result()   # (a bad token in the last step raises here)
+        # (a bad token in the last step raises here)
+        train_loss += pending.result()
     if loss is not None:
         logger.info(
             f'Epoch {epoch} finished, \t Training Loss = {loss.item():.4f},'

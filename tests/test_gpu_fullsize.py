@@ -333,6 +333,52 @@ def test_batch_4096_rows_match_small_batch():
     assert torch.equal(toks_s.cpu(), r_toks)
 
 
+def test_sampling_at_batch_4096_rows_match_oracle():
+    """SamplingSearch.step at the benchmarked decode batch (config 5: B=4096,
+    temperature 0.8): logits_choose_kernel runs a 256-block grid there, 5 blocks
+    at the B=70 test above.  Rows 0, 1023, 2048, 4095 of a 20-token generation
+    against the oracle replaying those four rows with the draws the device
+    hashes from (seed, step, GLOBAL row) regenerated in numpy: tokens bit for
+    bit, per-step logits within tolerance."""
+    import paccmann_chemistry_amd as P
+    rows = [0, 1023, 2048, 4095]
+    p = dict(CONFIG, batch_size=4096)
+    temperature, seed, gen_len = 0.8, 20261111, 20
+    sd = W.make_state_dict(p, 4310)
+    z = torch.from_numpy(np.random.default_rng(4311).standard_normal(
+        (4096, p['latent_dim'])).astype(np.float32))
+    prime = torch.tensor([2])
+    big = _build_vae(p, sd, train=False)
+    with torch.no_grad():
+        tokens, logits = big.decoder.generate_from_latent(
+            z.unsqueeze(0).to(_dev()), prime.to(_dev()), torch.tensor([3]),
+            search=P.SamplingSearch(temperature=temperature),
+            generate_len=gen_len, seed=seed, return_logits=True)
+    big.check_tokens()
+    tokens, logits = tokens.cpu()[rows], logits.cpu()[:, rows]
+    step_box = {'i': 0}
+
+    def chooser(step_logits):
+        i = step_box['i']
+        step_box['i'] += 1
+        u = _uniform(seed, (np.uint64(i) << np.uint64(32)) |
+                     np.asarray(rows, dtype=np.uint64))
+        probs = O.sampling_probabilities(step_logits, temperature)
+        cum = torch.cumsum(probs.double(), dim=1).numpy()
+        above = cum > u[:, None].astype(np.float64)
+        pick = above.argmax(axis=1)
+        pick[~above.any(axis=1)] = cum.shape[1] - 1
+        return torch.from_numpy(pick).view(-1, 1)
+
+    with torch.no_grad():
+        r_tokens, r_logits = O.generate_from_latent(
+            O.sub_params(sd, 'decoder'), z[rows], prime, gen_len,
+            p['stack_depth'], True, chooser)
+    assert torch.equal(tokens, r_tokens)
+    assert _rel_to_max(logits, r_logits) < LOGIT_TOL
+    assert (r_tokens[:, 1:] != r_logits.argmax(dim=2).t()).any()
+
+
 def test_large_stack_gradients_and_limit():
     """Stack sizes beyond the tuned 50x50: a 64x64 stack (one row per block in
     both stack kernels) trains with oracle-matching gradients; a stack whose
@@ -384,6 +430,7 @@ def test_large_stack_gradients_and_limit():
 @pytest.mark.parametrize('env', [
     {'PCM_PERSIST': '1'},
     {'PCM_CHAINS': '2'},
+    {'PCM_CHAINS': '2', 'PCM_DW_CUTS': '45,75,90'},
     {'PCM_FUSE_STACK': '1'},
     {'PCM_ROW_SKIP': '0'},
 ])

@@ -316,6 +316,55 @@ def test_one_model_serves_independent_batches_on_several_streams():
         assert torch.equal(gen[k], want[4])
 
 
+def test_pipelined_loops_keep_generated_inputs_alive():
+    """the batches may come from a lazy generator that allocates
+    each one on the fly and keeps no reference.  The stream ring must hold the
+    input until the caller's stream is ordered behind the side stream's reads;
+    otherwise the caching allocator hands the block to the next batch (here:
+    to the scribble tensor allocated right after every yield) while the encoder
+    on the side stream still reads its tokens at every step.  Also: the loops
+    check the token status once after draining (the reference's embedding
+    lookup raises for ids outside the vocabulary)."""
+    import paccmann_chemistry_amd as P
+    from oracle import weights as W
+    p = {
+        'latent_dim': 16, 'rnn_cell_size': 64, 'embedding_size': 20,
+        'vocab_size': 20, 'stack_width': 6, 'stack_depth': 5, 'n_layers': 2,
+        'dropout': 0.0, 'batch_size': 256, 'batch_mode': 'padded',
+        'embedding': 'one_hot', 'use_stack': True, 'bidirectional': False
+    }
+    vae = _build_vae(p, W.make_state_dict(p, 5200), train=False)
+    dev = _dev()
+    steps, batch, n = 64, 256, 6
+    host = [W.synthetic_tokens(steps, batch, 20, 5201 + k) for k in range(n)]
+
+    with torch.no_grad():
+        want = [vae.encode(t.to(dev)) for t in host]
+    torch.cuda.synchronize()
+
+    def lazy():
+        for t in host:
+            yield t.to(dev)       # the only reference is the generator's
+            # same size and dtype as a token batch: takes the freed block if
+            # the ring let go of it; its fill runs on the caller's stream
+            scribble = torch.full((steps, batch), 7, dtype=torch.int64,
+                                  device=dev)
+            del scribble
+
+    with torch.no_grad():
+        got = list(P.encode_batches(vae, lazy(), streams=3))
+    torch.cuda.synchronize()
+    for (mu, logvar), (mu_w, logvar_w) in zip(got, want):
+        assert torch.equal(mu, mu_w) and torch.equal(logvar, logvar_w)
+
+    bad = host[1].clone()
+    bad[3, 5] = 20                # one id outside the vocabulary
+    with torch.no_grad(), pytest.raises(RuntimeError, match='out of range'):
+        list(P.encode_batches(vae, [host[0].to(dev), bad.to(dev)], streams=2))
+    with torch.no_grad():         # the flag was consumed; a clean loop passes
+        list(P.encode_batches(vae, [host[0].to(dev)], streams=2))
+
+
 def test_determinism_bitwise():
     """Same inputs twice => bitwise identical loss and gradients."""
     g = Golden('vae_odd_padded')

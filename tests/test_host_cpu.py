@@ -360,3 +360,49 @@ def test_packed_to_padded_follows_stop_tokens():
     assert torch.equal(packed_to_padded(outs), want)
     with pytest.raises(ValueError):
         packed_to_padded([outs[0], outs[0][:2]], steps)   # no STOP seen yet
+
+
+def _bench_dry_run(*flags, env_extra=None):
+    """bench.py's launcher / rendezvous / reduction legs on the CPU
+    (PCM_BENCH_DRYRUN=1: gloo, no GPU, no library call)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PCM_BENCH_DRYRUN='1')
+    for key in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(key, None)
+    env.update(env_extra or {})
+    return subprocess.run(
+        [sys.executable, os.path.join(root, 'bench.py')] + list(flags),
+        env=env, capture_output=True, text=True, timeout=300
+    ), json
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` (no rendezvous in the environment) starts
+    two ranks itself; the line's n_gpus equals --gpus."""
+    done, json = _bench_dry_run('--gpus', '2', '--steps', '1', '--warmup', '0')
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [l for l in done.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, done.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['ranks_seen'] == 2
+    assert line['scaling'] == 'weak' and line['global_batch'] == 1024
+    assert line['max_elapsed'] == pytest.approx(0.002)   # MAX over ranks
+
+
+def test_bench_strong_scaling_splits_the_global_batch():
+    done, json = _bench_dry_run('--gpus', '2', '--scaling', 'strong')
+    assert done.returncode == 0, done.stderr[-2000:]
+    line = json.loads(
+        [l for l in done.stdout.splitlines() if l.startswith('{')][0])
+    assert line['scaling'] == 'strong'
+    assert line['batch_per_gpu'] == 2048 and line['global_batch'] == 4096
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    done, _ = _bench_dry_run('--gpus', '4', env_extra={
+        'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert done.returncode != 0
+    assert '--gpus 4 but WORLD_SIZE=1' in done.stderr

@@ -94,5 +94,92 @@ def test_softmax_ce_static_rejects_oversize():
     assert rc == -1
     msg = lib.pcm_last_error().decode()
     assert 'static maximum' in msg and str(1 << 20) in msg
-    # the largest accepted shape is exactly the maximum
-    assert ctypes.c_int(1 << 20).value == 1048576
+
+
+def test_softmax_ce_static_allocates_nothing_and_takes_the_maximum():
+    """The property the entry point exists for: device memory is the same
+    before and after a call (torch's allocator statistics AND the driver's free
+    memory), at the largest accepted shape, T*B + T == 2^20 floats of scratch.
+    pcm_device_check() resolves the array's address beforehand, as the header
+    asks of callers that will capture."""
+    from paccmann_chemistry_amd import _lib
+    from paccmann_chemistry_amd._lib import check, ptr, stream_ptr
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    steps, batch, vocab = 1024, 1023, 2
+    assert steps * batch + steps == 1 << 20
+    rng = np.random.default_rng(4)
+    logits = torch.from_numpy(
+        rng.standard_normal((steps, batch, vocab)).astype(np.float32)).to(dev)
+    targets = torch.from_numpy(
+        rng.integers(0, vocab, size=(steps, batch), dtype=np.int64)).to(dev)
+    loss = torch.zeros(1, device=dev)
+    ref_loss = torch.zeros(1, device=dev)
+    scratch = torch.empty(steps * batch + steps, device=dev)
+    check(lib.pcm_device_check(), 'pcm_device_check')
+    check(lib.pcm_softmax_ce(
+        ptr(logits), ptr(targets), None, None, steps, batch, vocab,
+        ptr(ref_loss), None, None, ptr(scratch), None, stream_ptr(dev)),
+        'pcm_softmax_ce')
+    torch.cuda.synchronize()
+    before = (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev),
+              torch.cuda.mem_get_info(dev)[0])
+    for _ in range(3):
+        check(lib.pcm_softmax_ce_static(
+            ptr(logits), ptr(targets), None, None, steps, batch, vocab,
+            ptr(loss), None, None, None, stream_ptr(dev)),
+            'pcm_softmax_ce_static')
+    torch.cuda.synchronize()
+    after = (torch.cuda.memory_allocated(dev), torch.cuda.memory_reserved(dev),
+             torch.cuda.mem_get_info(dev)[0])
+    assert after == before
+    assert torch.equal(loss.cpu(), ref_loss.cpu())
+    # one float more is refused
+    rc = lib.pcm_softmax_ce_static(
+        ptr(logits), ptr(targets), None, None, steps, batch + 1, vocab,
+        ptr(loss), None, None, None, stream_ptr(dev))
+    assert rc == -1
+
+
+def test_softmax_ce_static_under_stream_capture():
+    """A caller the entry point is for: the call is recorded into a HIP graph
+    (no allocation is legal there) and replayed on fresh inputs."""
+    from paccmann_chemistry_amd import _lib
+    from paccmann_chemistry_amd._lib import check, ptr, stream_ptr
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    steps, batch, vocab = 12, 40, 33
+    rng = np.random.default_rng(5)
+    logits = torch.zeros(steps, batch, vocab, device=dev)
+    targets = torch.zeros(steps, batch, dtype=torch.int64, device=dev)
+    loss = torch.zeros(1, device=dev)
+    dlogits = torch.zeros_like(logits)
+    argmax = torch.zeros(batch, steps, dtype=torch.int64, device=dev)
+    check(lib.pcm_device_check(), 'pcm_device_check')   # address resolved here
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        check(lib.pcm_softmax_ce_static(
+            ptr(logits), ptr(targets), None, None, steps, batch, vocab,
+            ptr(loss), ptr(argmax), ptr(dlogits), None, stream_ptr(dev)),
+            'pcm_softmax_ce_static (captured)')
+    for seed in (6, 7):
+        rng = np.random.default_rng(seed)
+        logits.copy_(torch.from_numpy(rng.standard_normal(
+            (steps, batch, vocab)).astype(np.float32) * 2))
+        targets.copy_(torch.from_numpy(
+            rng.integers(0, vocab, size=(steps, batch), dtype=np.int64)))
+        graph.replay()
+        torch.cuda.synchronize()
+        want_loss = torch.zeros(1, device=dev)
+        want_d = torch.zeros_like(logits)
+        want_a = torch.zeros_like(argmax)
+        scratch = torch.empty(steps * batch + steps, device=dev)
+        check(lib.pcm_softmax_ce(
+            ptr(logits), ptr(targets), None, None, steps, batch, vocab,
+            ptr(want_loss), ptr(want_a), ptr(want_d), ptr(scratch), None,
+            stream_ptr(dev)), 'pcm_softmax_ce')
+        torch.cuda.synchronize()
+        assert torch.equal(loss, want_loss)
+        assert torch.equal(argmax, want_a)
+        assert torch.equal(dlogits, want_d)
