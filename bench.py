@@ -20,6 +20,14 @@ kernel trace reports.  `roofline` is the family with the largest summed time,
 rocprofv3 PMC passes (profiles/pmc_traffic.json), not a live measurement;
 `cpu_baseline` times the CPU oracle (oracle/stackgru_oracle.py, kind "port") on
 a bounded sample on rank 0.
+
+`python bench.py --gpus N` with N > 1 and no rendezvous in the environment starts
+the N ranks itself (launch_ranks); `--scaling strong` splits BASELINE.json config
+3's global batch of 4096 over them (weak, the default: --batch sequences on every
+GPU).  At N = 1 the line also carries `inference` (configs 4 and 5: encoder-only
+and greedy / temperature-0.8 decode molecules/s at batch 4096, each with its MFMA
+roofline and a CPU baseline) and `ragged_training` (packed mode on ragged
+lengths), measured after the timed training steps (--inference 0: off).
 """
 import argparse
 import ctypes
@@ -230,6 +238,227 @@ def cpu_baseline(p, cpu_batch):
     }
 
 
+# ---- secondary workloads (BASELINE.json configs 4 and 5) -----------
+ENCODER_FLOP_PER_MOLECULE = 4.94e6 * SEQ_LEN   # 593 MFLOP at T = 120
+DECODE_FLOP_PER_TOKEN = 5.00e6                 # 0.50 GFLOP / molecule at 100
+
+
+def _time_batches(fn, batches, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(batches):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / batches
+
+
+def _mfma_roofline(kernel, flop_per_s):
+    return {'bound': 'mfma', 'kernel': kernel, 'achieved': flop_per_s / 1e12,
+            'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': flop_per_s / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            'note': 'whole workload: molecules/s x algorithmic FLOP per '
+                    'molecule (SURVEY 8d) against the fp32 MFMA peak'}
+
+
+def inference_cpu_baseline(p, batch=512, generate_len=100):
+    """The oracle on the host cores for the two inference workloads, bounded:
+    one warm-up + one timed call each at batch 512."""
+    from oracle import stackgru_oracle as O
+    from paccmann_chemistry_amd import synthetic as W
+    O.ATEN_CELL = True
+    threads = torch.get_num_threads()
+    q = dict(p, batch_size=batch)
+    sd = W.make_state_dict(q, 1234)
+    tokens = W.synthetic_tokens(SEQ_LEN, batch, q['vocab_size'], 99)
+    z = torch.randn(batch, q['latent_dim'],
+                    generator=torch.Generator().manual_seed(4321))
+    out = {}
+    with torch.no_grad():
+        for name, fn in (
+            ('encoder', lambda: O.encoder_forward(
+                O.sub_params(sd, 'encoder'), tokens, q['stack_depth'])),
+            ('greedy', lambda: O.generate_from_latent(
+                O.sub_params(sd, 'decoder'), z, torch.tensor([2]),
+                generate_len, q['stack_depth'])),
+        ):
+            fn()
+            t0 = time.perf_counter()
+            fn()
+            sec = time.perf_counter() - t0
+            out[name] = {
+                'value': batch / sec, 'unit': 'molecules/s', 'cores': threads,
+                'kind': 'port',
+                'sample': f'oracle, batch {batch}, 1 warm-up + 1 timed call, '
+                          f'{threads} torch threads',
+            }
+    return out
+
+
+def inference_lines(dev, batch=4096, batches=5, generate_len=100, streams=1,
+                    cpu=True, host_lists=True):
+    """Encoder-only molecules/s (config 4: generate_latent_codes-style
+    mu / logvar) and decode molecules/s (config 5: greedy and temperature 0.8
+    from prior latents) at batch 4096, fp32, on a bounded sample of the named
+    10 M / 1 M sets (the same batch shape repeated).  Entries carry the MFMA
+    roofline of the whole workload and, for the workloads the oracle finishes in
+    seconds, a CPU baseline."""
+    import paccmann_chemistry_amd as P
+    from paccmann_chemistry_amd import synthetic as W
+    from paccmann_chemistry_amd.training import get_data_preparation
+    p = dict(PARAMS, batch_size=batch)
+    torch.manual_seed(1234)
+    vae = P.TeacherVAE(P.StackGRUEncoder(p), P.StackGRUDecoder(p)).to(dev)
+    vae.eval()
+    base = {'n_gpus': 1, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'batches': batches, 'streams': streams,
+            'unit': 'molecules/s'}
+    cpu_base = inference_cpu_baseline(PARAMS) if cpu else {}
+    lines = []
+
+    def entry(metric, sec, workload, flop_per_molecule, kernel, **extra):
+        value = batch / sec
+        lines.append(dict(
+            base, metric=metric, value=value, ms_per_batch=sec * 1e3,
+            config={'workload': workload},
+            roofline=_mfma_roofline(kernel, value * flop_per_molecule),
+            **extra))
+
+    # ---- config 4: encoder only ---------------------------------------------
+    tokens = W.synthetic_tokens(SEQ_LEN, batch, p['vocab_size'], 1234).to(dev)
+    with torch.no_grad():
+        if streams > 1:
+            def run_enc():
+                for _ in P.encode_batches(vae, [tokens] * (2 * streams),
+                                          streams=streams):
+                    pass
+            sec = _time_batches(run_enc, max(1, batches // 2), 1) / (2 * streams)
+        else:
+            sec = _time_batches(lambda: vae.encode(tokens), batches, 2)
+    entry('encoder-only molecules/sec (mu/logvar)', sec,
+          f'StackGRUEncoder mu/logvar, no_grad, batch {batch}, seq len '
+          f'{SEQ_LEN}, padded, tokens resident on the device',
+          ENCODER_FLOP_PER_MOLECULE, 'gru_cell_fwd64_kernel + stack step',
+          tokens_per_s=batch * SEQ_LEN / sec, cpu_baseline=cpu_base.get('encoder'))
+    if host_lists:
+        # the loop of examples/generate_latent_codes.py:113-125: every batch
+        # arrives as the DataLoader's list of 1-D host tensors and goes through
+        # data_preparation (pinned staging copy + one launch) before encode
+        host = W.synthetic_tokens(SEQ_LEN, batch, p['vocab_size'], 1236)
+        as_list = [host[:, b].contiguous() for b in range(batch)]
+        prep = get_data_preparation('padded')
+        n_lists = 2 * max(streams, 3)
+
+        def run_lists():
+            with torch.no_grad():
+                for _ in P.encode_batches(vae, [as_list] * n_lists,
+                                          data_preparation=prep,
+                                          streams=max(streams, 3), device=dev):
+                    pass
+        sec = _time_batches(run_lists, 1, 1) / n_lists
+        entry('encoder-only molecules/sec (mu/logvar)', sec,
+              f'as above, but every batch handed over as a list of {batch} '
+              f'host tensors through data_preparation (host -> device copy '
+              f'inside the timed region), encode_batches over '
+              f'{max(streams, 3)} streams',
+              ENCODER_FLOP_PER_MOLECULE, 'gru_cell_fwd64_kernel + stack step',
+              tokens_per_s=batch * SEQ_LEN / sec, host_input=True)
+
+    lengths = sorted(W.ragged_lengths(batch, SEQ_LEN, 4321), reverse=True)
+    ragged = W.synthetic_tokens(SEQ_LEN, batch, p['vocab_size'], 1235, lengths)
+    packed = torch.nn.utils.rnn.pack_sequence(
+        [ragged[:n, b] for b, n in enumerate(lengths)]).to(dev)
+    vae.encoder.set_batch_mode('packed')
+    with torch.no_grad():
+        sec = _time_batches(lambda: vae.encode(packed), batches, 2)
+    vae.encoder.set_batch_mode('padded')
+    real = float(sum(lengths))
+    entry('encoder-only molecules/sec (mu/logvar)', sec,
+          f'StackGRUEncoder mu/logvar, no_grad, batch {batch}, ragged lengths '
+          f'~N(60,20) clipped to [10,{SEQ_LEN}], packed',
+          4.94e6 * real / batch, 'gru_cell_fwd*_kernel + stack step',
+          tokens_per_s=real / sec)
+
+    # ---- config 5: decode from prior latents --------------------------------
+    gen = torch.Generator(device='cpu').manual_seed(4321)
+    z = torch.randn(1, batch, p['latent_dim'], generator=gen).to(dev)
+    prime = torch.tensor([2], device=dev)
+    end = torch.tensor([3], device=dev)
+    for name, search in (('greedy', P.GreedySearch()),
+                         ('sampling T=0.8', P.SamplingSearch(temperature=0.8))):
+        def run():
+            return vae.decoder.generate_from_latent(
+                z, prime, end, search=search, generate_len=generate_len,
+                seed=99)
+        if streams > 1:
+            def run_gen():
+                for _ in P.generate_batches(
+                        vae, [z] * (2 * streams), prime, end,
+                        generate_len=generate_len, search=search,
+                        streams=streams, seed=99):
+                    pass
+            sec = _time_batches(run_gen, max(1, batches // 2), 1) / (2 * streams)
+        else:
+            sec = _time_batches(run, batches, 2)
+        entry(f'decode molecules/sec ({name})', sec,
+              f'StackGRUDecoder.generate_from_latent, {name}, batch {batch}, '
+              f'prime [2], generate_len {generate_len}',
+              DECODE_FLOP_PER_TOKEN * generate_len,
+              'gru_cell_fwd64_kernel + stack step + logits_choose_kernel',
+              tokens_per_s=batch * generate_len / sec,
+              cpu_baseline=cpu_base.get('greedy') if name == 'greedy' else None)
+    vae.check_tokens()
+    return lines
+
+
+def ragged_training_line(dev, batch, steps=6, warmup=2):
+    """The training step on ragged packed batches (lengths ~N(60,20)), the
+    reference's default batch_mode (example_params.json:26); tokens/s counts
+    the REAL tokens."""
+    import paccmann_chemistry_amd as P
+    from paccmann_chemistry_amd import dp
+    from paccmann_chemistry_amd.ops import KLDivFn
+    from paccmann_chemistry_amd.utils import kl_weight
+    from paccmann_chemistry_amd import synthetic as W
+    p = dict(PARAMS, batch_size=batch, batch_mode='packed')
+    torch.manual_seed(1234)
+    vae = P.TeacherVAE(P.StackGRUEncoder(p), P.StackGRUDecoder(p)).to(dev)
+    vae.train()
+    lengths = sorted(W.ragged_lengths(batch, SEQ_LEN, 4321), reverse=True)
+    cpu_tokens = W.synthetic_tokens(SEQ_LEN, batch, p['vocab_size'], 1234,
+                                    lengths)
+    cpu_targets = W.shifted_targets(cpu_tokens)
+    pack = torch.nn.utils.rnn.pack_sequence
+    tokens = pack([cpu_tokens[:n, b] for b, n in enumerate(lengths)]).to(dev)
+    targets = pack([cpu_targets[:n, b] for b, n in enumerate(lengths)]).to(dev)
+    buckets = dp.GradientBuckets(vae, overlap=False)
+    optimizer = dp.FlatAdam(buckets, lr=LR)
+    box = [0]
+
+    def step():
+        buckets.zero_grad()
+        dec_loss, mu, logvar = vae(tokens, tokens, targets)
+        kl = KLDivFn.apply(mu, logvar)
+        loss = dec_loss + kl_weight(box[0], KL_GROWTH) * kl
+        loss.backward()
+        buckets.finish()
+        optimizer.step()
+        box[0] += 1
+    sec = _time_batches(step, steps, warmup)
+    vae.check_tokens()
+    real = int(sum(lengths))
+    return {
+        'metric': 'SMILES tokens/sec (train fwd+bwd)', 'value': real / sec,
+        'unit': 'tokens/s', 'ms_per_step': sec * 1e3, 'steps': steps,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'training step, batch {batch}, packed mode, '
+                               f'ragged lengths ~N(60,20) in [10,{SEQ_LEN}] '
+                               f'({real} real tokens per batch)'},
+        'roofline': _mfma_roofline('whole step', real / sec * 29.8e6),
+    }
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -435,6 +664,14 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(p, args.cpu_batch)
+        inference = ragged = None
+        if args.inference and world == 1 and not bf16 and not args.ragged:
+            # configs 4 and 5 and the ragged training step, after the timed
+            # region; the training model's buffers are released first
+            torch.cuda.empty_cache()
+            inference = inference_lines(dev, cpu=not args.no_cpu_baseline)
+            torch.cuda.empty_cache()
+            ragged = ragged_training_line(dev, args.batch)
         line = {
             'metric': 'SMILES tokens/sec (train fwd+bwd)',
             'value': value, 'unit': 'tokens/s', 'n_gpus': world,
@@ -462,6 +699,7 @@ def main():
             'roofline': roofline, 'roofline_kernels': entries,
             'step_roofline': step_roofline, 'cpu_baseline': cpu,
             'final_loss': final_loss,
+            'inference': inference, 'ragged_training': ragged,
         }
         print(json.dumps(line), flush=True)
     if use_dist:
