@@ -80,16 +80,52 @@ def global_step_weights(lengths, steps, batch, device=None):
     return weights if device is None else weights.to(device)
 
 
+class GradSink:
+    """Where the library writes one parameter's gradient: a view of its
+    bucket's flat buffer.  The autograd Functions of ops.py hand ``view`` to
+    the C ABI as the gradient output (``=`` on the first write after
+    ``zero_grad``, ``+=`` on later ones) and return None for the parameter, so
+    no AccumulateGrad add -- one small launch per parameter and step -- runs."""
+
+    __slots__ = ('view', 'written', 'counted', 'bucket', 'owner')
+
+    def __init__(self, view, bucket, owner):
+        self.view, self.bucket, self.owner = view, bucket, owner
+        self.written = self.counted = False
+
+    def usable_by(self, param):
+        """True while ``param.grad`` is this sink's view (the caller follows
+        the GradientBuckets.zero_grad protocol)."""
+        grad = param.grad
+        return grad is not None and grad.data_ptr() == self.view.data_ptr()
+
+    def mark_written(self):
+        """The library has enqueued this gradient's write into the view."""
+        self.written = True
+        if not self.counted:
+            self.counted = True
+            self.owner._on_grad(self.bucket)
+
+
+ALIGN = 64   # floats: every view starts on a 256-byte boundary
+
+
 class GradientBuckets:
     """Flat gradient buckets of a TeacherVAE, reduced with async all-reduce.
 
     ``param.grad`` of every parameter is a view of its bucket's flat gradient
     buffer, so a bucket's gradients are contiguous and no flatten / unflatten
-    copies are needed (FlatAdam below does the same for the parameters)."""
+    copies are needed (FlatAdam below does the same for the parameters).  With
+    ``direct`` (the default) every parameter also carries a ``GradSink``: the
+    reverse pass writes its gradients straight into the views."""
 
-    def __init__(self, model, overlap=True, force_collective=False):
+    def __init__(self, model, overlap=True, force_collective=False,
+                 direct=None):
         self.model = model
         self.overlap = overlap
+        if direct is None:   # the library only ever writes device memory
+            direct = all(p.is_cuda for p in model.parameters())
+        self.direct = direct
         # issue the all-reduce even in a one-rank group (rehearses the RCCL
         # path on a single GPU; the sum over one rank is the identity)
         self.force_collective = force_collective
@@ -97,50 +133,71 @@ class GradientBuckets:
                if n.startswith('decoder.') and p.requires_grad]
         enc = [p for n, p in model.named_parameters()
                if not n.startswith('decoder.') and p.requires_grad]
-        self.buckets = [self._make_bucket(dec), self._make_bucket(enc)]
         self._pending = []
         self._hooks = []
+        self.buckets = [self._make_bucket(dec), self._make_bucket(enc)]
         if overlap:
             self._install_hooks()
 
-    @staticmethod
-    def _make_bucket(params):
+    def _make_bucket(self, params):
         if not params:
             return None
-        total = sum(p.numel() for p in params)
-        dev, dtype = params[0].device, params[0].dtype
-        flat = torch.zeros(total, device=dev, dtype=dtype)
-        views, off = [], 0
+        offsets, off = [], 0
         for p in params:
-            views.append(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
-        return {'params': params, 'flat': flat, 'views': views, 'ready': 0}
+            offsets.append(off)
+            off += -(-p.numel() // ALIGN) * ALIGN
+        dev, dtype = params[0].device, params[0].dtype
+        flat = torch.zeros(off, device=dev, dtype=dtype)
+        views = [flat[o:o + p.numel()].view_as(p)
+                 for p, o in zip(params, offsets)]
+        bucket = {'params': params, 'flat': flat, 'views': views,
+                  'offsets': offsets, 'ready': 0, 'sinks': []}
+        for p, view in zip(params, views):
+            sink = GradSink(view, bucket, self)
+            bucket['sinks'].append(sink)
+            if self.direct:
+                p._pcm_grad_sink = sink
+        return bucket
 
     def _install_hooks(self):
         """Launch a bucket's all-reduce as soon as its last gradient has been
-        accumulated (post-accumulate-grad hooks)."""
+        accumulated (post-accumulate-grad hooks; gradients written through a
+        GradSink report by hand, see GradSink.mark_written)."""
         for bucket in self.buckets:
             if bucket is None:
                 continue
-            for p in bucket['params']:
+            for p, sink in zip(bucket['params'], bucket['sinks']):
                 self._hooks.append(
                     p.register_post_accumulate_grad_hook(
-                        lambda param, b=bucket: self._on_grad(b)
+                        lambda param, b=bucket, s=sink: self._on_hook(b, s)
                     )
                 )
 
+    def _on_hook(self, bucket, sink):
+        # AccumulateGrad ran for this parameter (a producer that did not use
+        # the sink); count it once per step
+        sink.written = True
+        if not sink.counted:
+            sink.counted = True
+            self._on_grad(bucket)
+
     def _on_grad(self, bucket):
+        if not self.overlap:
+            return
         bucket['ready'] += 1
         if bucket['ready'] == len(bucket['params']):
             self._launch(bucket)
 
     def _gather_flat(self, bucket):
-        for p, view in zip(bucket['params'], bucket['views']):
+        for p, view, sink in zip(bucket['params'], bucket['views'],
+                                 bucket['sinks']):
             if p.grad is None:
                 view.zero_()
+                p.grad = view
             elif p.grad.data_ptr() != view.data_ptr():
                 view.copy_(p.grad)
                 p.grad = view
+            sink.written = True
         return bucket['flat']
 
     def _launch(self, bucket):
@@ -165,12 +222,19 @@ class GradientBuckets:
                 bucket['ready'] = 0
 
     def zero_grad(self):
+        """Start a step: the flat buffers are cleared (one fill per bucket) and
+        every ``param.grad`` is its bucket view again.  The library's first
+        write of a step into a view overwrites it (GradSink), later ones add;
+        a gradient that arrives through AccumulateGrad, or that the caller
+        copies into ``param.grad`` by hand, lands on the zeros as usual."""
         for bucket in self.buckets:
             if bucket is None:
                 continue
-            bucket['flat'].zero_()
             bucket['ready'] = 0
-            for p, view in zip(bucket['params'], bucket['views']):
+            bucket['flat'].zero_()
+            for p, view, sink in zip(bucket['params'], bucket['views'],
+                                     bucket['sinks']):
+                sink.written = sink.counted = False
                 p.grad = view
 
 
@@ -190,14 +254,12 @@ class FlatAdam:
             if bucket is None:
                 self.state.append(None)
                 continue
-            flat = torch.empty_like(bucket['flat'])
-            off = 0
+            flat = torch.zeros_like(bucket['flat'])
             with torch.no_grad():
-                for p in bucket['params']:
+                for p, off in zip(bucket['params'], bucket['offsets']):
                     view = flat[off:off + p.numel()].view_as(p)
                     view.copy_(p.data)
                     p.data = view
-                    off += p.numel()
             self.state.append({
                 'param': flat,
                 'exp_avg': torch.zeros_like(flat),

@@ -93,6 +93,27 @@ def _active_rows(lengths, steps):
     return (lens.view(1, -1) > steps_idx).sum(dim=1).to(torch.int32).contiguous()
 
 
+def _direct_sinks(params, needs):
+    """Gradient sinks (dp.GradSink) of ``params`` when EVERY wanted gradient
+    can be written straight into its parameter's bucket view, all in the same
+    state: (sinks, accumulate) with accumulate = 0 for the first write since
+    ``zero_grad`` and 1 for a later one; None when any of them must take the
+    ordinary route (a returned tensor that AccumulateGrad adds)."""
+    sinks, states = [], set()
+    for param, need in zip(params, needs):
+        if param is None or not need:
+            sinks.append(None)
+            continue
+        sink = getattr(param, '_pcm_grad_sink', None)
+        if sink is None or not sink.usable_by(param):
+            return None
+        sinks.append(sink)
+        states.add(sink.written)
+    if len(states) != 1:
+        return None
+    return sinks, 1 if states.pop() else 0
+
+
 def _host_ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -118,6 +139,7 @@ class StackGRUSequenceFn(torch.autograd.Function):
             tokens = tokens.long()
         training = 1 if cfg['training'] else 0
         hid = dims.hidden
+        ctx.params = weights
         weights = [None if w is None else _f32(w, 'weight').contiguous()
                    for w in weights]
         wstruct = _lib.make_params(weights, n_layers)
@@ -202,10 +224,16 @@ class StackGRUSequenceFn(torch.autograd.Function):
         weights = ctx.weights
         wstruct = _lib.make_params(weights, n_layers)
         needs = ctx.needs_input_grad[6:]
-        grads = [
-            torch.empty_like(w) if (w is not None and need) else None
-            for w, need in zip(weights, needs)
-        ]
+        direct = _direct_sinks(ctx.params, needs)
+        if direct is not None:
+            sinks, accumulate = direct
+            grads = [None if s is None else s.view for s in sinks]
+        else:
+            accumulate = 0
+            grads = [
+                torch.empty_like(w) if (w is not None and need) else None
+                for w, need in zip(weights, needs)
+            ]
         gstruct = _lib.make_params(grads, n_layers)
         d_out_ld = 0
         if d_out is not None:
@@ -237,8 +265,8 @@ class StackGRUSequenceFn(torch.autograd.Function):
                 float(cfg['dropout']),
                 int(cfg['seed']), ptr(saved), saved.numel() * 4, ptr(d_out),
                 d_out_ld, ptr(d_h_final), ptr(d_stack_final), ptr(d_h0),
-                ptr(d_stack0), ctypes.byref(gstruct), 0, ptr(scratch), sbytes,
-                stream_ptr(dev)
+                ptr(d_stack0), ctypes.byref(gstruct), accumulate, ptr(scratch),
+                sbytes, stream_ptr(dev)
             ), 'pcm_stackgru_backward'
         )
         ctx.saved_buf = None
@@ -247,6 +275,13 @@ class StackGRUSequenceFn(torch.autograd.Function):
             grads[4][pad].zero_()  # nn.Embedding(padding_idx=...) semantics
         if d_h0 is not None and ctx.h0_broadcast:
             d_h0 = d_h0.sum(dim=0)
+        if direct is not None:
+            # written in place: nothing for AccumulateGrad to add
+            for sink in sinks:
+                if sink is not None:
+                    sink.mark_written()
+            grads = [None] * len(grads)
+        ctx.params = None
         return (None, None, None, d_h0, d_stack0, None) + tuple(grads)
 
 
@@ -275,6 +310,7 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         lib = load()
         _f32(x, 'linear input')
+        weight_param, bias_param = weight, bias
         weight = _f32(weight, 'linear weight').contiguous()
         n, k = weight.shape
         x2, m, ldx = _rows2d(x, 'linear input')
@@ -291,6 +327,7 @@ class LinearFn(torch.autograd.Function):
         ctx.ldx = ldx
         ctx.in_shape = x.shape
         ctx.has_bias = bias is not None
+        ctx.params = (weight_param, bias_param)
         return y
 
     @staticmethod
@@ -302,18 +339,31 @@ class LinearFn(torch.autograd.Function):
         dev = dy.device
         need_x, need_w, need_b = ctx.needs_input_grad
         dx = torch.empty(m, k, device=dev) if need_x else None
-        dw = torch.empty(n, k, device=dev) if need_w else None
-        db = torch.empty(n, device=dev) if (need_b and ctx.has_bias) else None
+        need_b = need_b and ctx.has_bias
+        direct = _direct_sinks(ctx.params, (need_w, need_b))
+        accumulate = 0
+        if direct is not None:
+            (sink_w, sink_b), accumulate = direct
+            dw = sink_w.view if sink_w is not None else None
+            db = sink_b.view if sink_b is not None else None
+        else:
+            dw = torch.empty(n, k, device=dev) if need_w else None
+            db = torch.empty(n, device=dev) if need_b else None
         scratch = _linear_scratch(dev, m, n, k)
         check(
             lib.pcm_linear_backward(
                 ptr(x2), ctx.ldx, ptr(weight), ptr(dy2), None, lddy, ptr(dx),
-                k, ptr(dw), ptr(db), m, n, k, 0, ptr(scratch),
+                k, ptr(dw), ptr(db), m, n, k, accumulate, ptr(scratch),
                 scratch.numel() * 4, stream_ptr(dev)
             ), 'pcm_linear_backward'
         )
         if dx is not None:
             dx = dx.view(ctx.in_shape)
+        if direct is not None:
+            for sink in (sink_w, sink_b):
+                if sink is not None:
+                    sink.mark_written()
+            dw = db = None
         return dx, dw, db
 
 
@@ -333,6 +383,7 @@ class DecoderHeadFn(torch.autograd.Function):
         lib = load()
         _f32(out, 'decoder outputs')
         steps, batch, hid = out.shape
+        ctx.params = (weight, bias)
         weight = _f32(weight, 'output_layer.weight').contiguous()
         bias = _f32(bias, 'output_layer.bias').contiguous()
         vocab = weight.shape[0]
@@ -379,18 +430,30 @@ class DecoderHeadFn(torch.autograd.Function):
         dev = x2.device
         need_x, need_w, need_b = ctx.needs_input_grad[:3]
         dx = torch.empty(steps, batch, hid, device=dev) if need_x else None
-        dw = torch.empty(vocab, hid, device=dev) if need_w else None
-        db = torch.empty(vocab, device=dev) if need_b else None
+        direct = _direct_sinks(ctx.params, (need_w, need_b))
+        accumulate = 0
+        if direct is not None:
+            (sink_w, sink_b), accumulate = direct
+            dw = sink_w.view if sink_w is not None else None
+            db = sink_b.view if sink_b is not None else None
+        else:
+            dw = torch.empty(vocab, hid, device=dev) if need_w else None
+            db = torch.empty(vocab, device=dev) if need_b else None
         dloss = _f32(dloss, 'dloss').reshape(1).contiguous()
         scratch = _linear_scratch(dev, m, vocab, hid)
         check(
             lib.pcm_linear_backward(
                 ptr(x2), ctx.ldx, ptr(weight), ptr(ctx.dlogits), ptr(dloss),
-                vocab, ptr(dx), hid, ptr(dw), ptr(db), m, vocab, hid, 0,
-                ptr(scratch), scratch.numel() * 4, stream_ptr(dev)
+                vocab, ptr(dx), hid, ptr(dw), ptr(db), m, vocab, hid,
+                accumulate, ptr(scratch), scratch.numel() * 4, stream_ptr(dev)
             ), 'pcm_linear_backward(output_layer)'
         )
         ctx.dlogits = None
+        if direct is not None:
+            for sink in (sink_w, sink_b):
+                if sink is not None:
+                    sink.mark_written()
+            dw = db = None
         return dx, dw, db, None, None, None, None
 
 
