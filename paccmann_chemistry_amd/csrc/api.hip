@@ -241,6 +241,16 @@ int pcm_sg_layout(const pcm_dims *d, int steps, int training, int dropout,
     o->off_cspart =
         take(off, o->use_stack ? (size_t)o->B * (o->Hn / 16) * 64 : 0);
     o->off_cpre = take(off, persist ? (size_t)steps * o->B * 64 : 0);
+    {
+        size_t hf = 0, xdf = 0, xtf = 0, wf = 0;
+        if (persist && pcm_persist_fwd_mode() == 2)
+            pcm_persist2_fwd_regions(o->B, steps, &hf, &xdf, &xtf, &wf);
+        o->off_hfrag[0] = take(off, hf);
+        o->off_hfrag[1] = take(off, hf);
+        o->off_xdfrag = take(off, o->dropout ? xdf : 0);
+        o->off_xtfrag = take(off, xtf);
+        o->off_wfrag = take(off, wf);
+    }
     o->off_tokg = take(off, (size_t)o->V * 3 * o->Hn);
     for (int l = 0; l < o->L; ++l) {
         o->off_wpack[l] = take(off, (size_t)3 * o->Hn * o->Kp[l]);
@@ -696,8 +706,10 @@ int pcm_stackgru_forward(const pcm_dims *dims,
     // the tuned shape walks all steps in ONE persistent launch
     const bool persist = !active_rows && pcm_persist_fwd_supported(lay, lengths);
     if (persist) {
-        rc = pcm_launch_persist_fwd(lay, sv, weights, tokens, dropout_p, seed,
-                                    status, (unsigned *)(sv + lay.off_sync), st);
+        rc = (pcm_persist_fwd_mode() == 2 ? pcm_launch_persist2_fwd
+                                          : pcm_launch_persist_fwd)(
+            lay, sv, weights, tokens, dropout_p, seed, status,
+            (unsigned *)(sv + lay.off_sync), st);
         if (rc) return rc;
     }
     // one chain over the whole batch, or two half-batch chains on two streams

@@ -634,11 +634,18 @@ __global__ void persist_report_kernel(const unsigned *error, int32_t *status) {
 // ---- host side ----------------------------------------------------------------------------
 size_t pcm_persist_fwd_sync_words() { return 8 * 4 * SYNC_STRIDE + SYNC_STRIDE; }
 
-bool pcm_persist_fwd_supported(const SGLayout &lay, const int32_t *lengths) {
+int pcm_persist_fwd_mode() {
+    // PCM_PERSIST: 0 never, 1 the first persistent kernel (this file), 2 the
+    // role-split one (persist2_fwd.hip); unset: see pcm_persist_fwd_supported
     static const int mode = [] {
-        const char *e = getenv("PCM_PERSIST");   // 0: never, 1: whenever possible
+        const char *e = getenv("PCM_PERSIST");
         return e ? atoi(e) : -1;
     }();
+    return mode;
+}
+
+bool pcm_persist_fwd_supported(const SGLayout &lay, const int32_t *lengths) {
+    const int mode = pcm_persist_fwd_mode();
     if (mode == 0) return false;
     static const int cus = [] {
         int dev = 0, n = 0;
@@ -647,9 +654,11 @@ bool pcm_persist_fwd_supported(const SGLayout &lay, const int32_t *lengths) {
                                         dev);
         return n;
     }();
+    if (lengths || cus < 8 * PMEM) return false;
+    if (mode == 2) return pcm_persist2_fwd_shape_ok(lay);
     const bool shape = lay.H == PH && lay.L == 2 && lay.use_stack && lay.W <= PWP &&
                        lay.W >= 1 && 3 + lay.W <= 56 && lay.AVW <= 64 &&
-                       lay.B <= 8 * PROWS && !lengths && cus >= 8 * PMEM &&
+                       lay.B <= 8 * PROWS &&
                        LDS_FIXED_FLOATS + 4 * ((lay.DW + 3) & ~3) <= LDS_MAX_FLOATS;
     if (!shape) return false;
     // Measured on MI355X at batch 512: 48 us per step against 42.7 us

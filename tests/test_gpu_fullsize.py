@@ -429,6 +429,7 @@ def test_large_stack_gradients_and_limit():
 
 @pytest.mark.parametrize('env', [
     {'PCM_PERSIST': '1'},
+    {'PCM_PERSIST': '2'},
     {'PCM_CHAINS': '2'},
     {'PCM_CHAINS': '2', 'PCM_DW_CUTS': '45,75,90'},
     {'PCM_FUSE_STACK': '1'},
