@@ -670,6 +670,13 @@ def main():
             # region; the training model's buffers are released first
             torch.cuda.empty_cache()
             inference = inference_lines(dev, cpu=not args.no_cpu_baseline)
+            # the same workloads through the product's pipelined batch loops
+            # (inference.encode_batches / generate_batches: three independent
+            # batches in flight on three HIP streams, results bit-identical)
+            inference += [
+                e for e in inference_lines(dev, streams=3, cpu=False,
+                                           host_lists=False)
+                if 'ragged' not in e['config']['workload']]
             torch.cuda.empty_cache()
             ragged = ragged_training_line(dev, args.batch)
         line = {

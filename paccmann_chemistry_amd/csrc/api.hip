@@ -23,6 +23,11 @@ int pcm_launch_broadcast_token(const int64_t *src, int B, int64_t *next_tok,
                                int64_t *tokens_out, long long out_stride,
                                int out_col, hipStream_t stream);
 
+std::recursive_mutex &pcm_api_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
+
 // ---- errors -----------------------------------------------------------------------
 static thread_local char g_err[512] = "";
 
@@ -487,6 +492,7 @@ extern "C" {
 int pcm_version(void) { return 4; }
 
 int pcm_set_matmul_precision(int32_t mode) {
+    PCM_API_GUARD;
     PCM_REQUIRE(mode == 0 || mode == 1, PCM_EINVAL,
                 "set_matmul_precision: mode %d (0 = fp32, 1 = bf16 operands)",
                 (int)mode);
@@ -497,6 +503,7 @@ int pcm_set_matmul_precision(int32_t mode) {
 int pcm_get_matmul_precision(void) { return g_pcm_matmul_bf16; }
 
 int pcm_probe_enable(int32_t kernel_id, int32_t max_launches) {
+    PCM_API_GUARD;
     PCM_REQUIRE((kernel_id >= 0 && kernel_id <= PCM_K_DW_GEMM) ||
                     kernel_id == 11 || kernel_id == 12 || kernel_id == 51 ||
                     kernel_id == 52,
@@ -525,6 +532,7 @@ __global__ void pcm_empty_kernel(int *sink) {
 
 int pcm_probe_calibrate(int32_t launches, double *probe_us, double *chain_us,
                         void *stream) {
+    PCM_API_GUARD;
     PCM_REQUIRE(launches >= 8 && launches <= 4096 && probe_us && chain_us,
                 PCM_EINVAL, "probe_calibrate: bad args");
     hipStream_t st = (hipStream_t)stream;
@@ -570,6 +578,7 @@ int pcm_probe_calibrate(int32_t launches, double *probe_us, double *chain_us,
 }
 
 int pcm_probe_read(double *total_ms, int64_t *launches, int64_t *dropped) {
+    PCM_API_GUARD;
     probe_drain();
     if (total_ms) *total_ms = g_probe_ms;
     if (launches) *launches = g_probe_n;
@@ -580,6 +589,7 @@ int pcm_probe_read(double *total_ms, int64_t *launches, int64_t *dropped) {
 const char *pcm_last_error(void) { return g_err; }
 
 int pcm_device_check(void) {
+    PCM_API_GUARD;
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     PCM_REQUIRE(e == hipSuccess, PCM_EDEVICE, "no HIP device: %s",
@@ -632,6 +642,7 @@ int pcm_stackgru_forward(const pcm_dims *dims,
                          int32_t training, void *saved, size_t saved_bytes,
                          float *h_final, float *stack_final, int32_t *status,
                          void *stream) {
+    PCM_API_GUARD;
     SGLayout lay;
     // the layout always reserves the dropout slots so that saved_bytes() does
     // not depend on dropout_p; they are only written when dropout is active
@@ -795,6 +806,7 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                           float *d_h0, float *d_stack0,
                           const pcm_stackgru_params *grads, int32_t accumulate,
                           void *scratch, size_t scratch_bytes, void *stream) {
+    PCM_API_GUARD;
     SGLayout lay;
     int rc = pcm_sg_layout(dims, steps, 1, 1, &lay);
     if (rc) return rc;
@@ -1365,6 +1377,7 @@ int pcm_stackgru_backward(const pcm_dims *dims,
 int pcm_linear_forward(const float *x, int64_t ldx, const float *w,
                        const float *b, float *y, int64_t ldy, int32_t m,
                        int32_t n, int32_t k, void *stream) {
+    PCM_API_GUARD;
     PCM_REQUIRE(x && w && y && m > 0 && n > 0 && k > 0, PCM_EINVAL,
                 "linear_forward: bad args");
     GemmBatch gb;
@@ -1387,6 +1400,7 @@ int pcm_linear_backward(const float *x, int64_t ldx, const float *w,
                         float *dw, float *db, int32_t m, int32_t n, int32_t k,
                         int32_t accumulate, void *scratch,
                         size_t scratch_bytes, void *stream) {
+    PCM_API_GUARD;
     PCM_REQUIRE(dy && m > 0 && n > 0 && k > 0, PCM_EINVAL,
                 "linear_backward: bad args");
     hipStream_t st = (hipStream_t)stream;
@@ -1469,6 +1483,7 @@ int pcm_stackgru_generate(const pcm_dims *dims,
                           int64_t *tokens_out, float *logits_out,
                           void *workspace, size_t workspace_bytes,
                           int32_t *status, void *stream) {
+    PCM_API_GUARD;
     GenLayout g;
     int rc = gen_layout(dims, &g);
     if (rc) return rc;
@@ -1647,6 +1662,7 @@ int pcm_stackgru_generate_beam(const pcm_dims *dims,
                                double *beam_scores_out, void *workspace,
                                size_t workspace_bytes, int32_t *status,
                                void *stream) {
+    PCM_API_GUARD;
     BeamLayout bl;
     int rc = beam_layout(dims, beam_width, generate_len, &bl);
     if (rc) return rc;

@@ -14,6 +14,18 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define PCM_WAVE 64
 
+// ---- one host thread at a time inside the library ------------------------------
+// Every entry point that enqueues work takes this lock for the time it spends on
+// the HOST (microseconds: the kernels run asynchronously on the caller's
+// stream): the launch-duration probe, the mixed-precision switch, the per-device
+// side streams and the lazily created kernel attributes are process-wide state,
+// and callers do enter from two threads (autograd runs backward on its own
+// device thread).  Recursive: entry points call each other.
+#include <mutex>
+std::recursive_mutex &pcm_api_mutex();
+#define PCM_API_GUARD \
+    std::lock_guard<std::recursive_mutex> pcm_api_guard_(pcm_api_mutex())
+
 // ---- error plumbing -----------------------------------------------------------
 void pcm_set_error(const char *fmt, ...);
 int pcm_check_launch(const char *what);

@@ -804,6 +804,7 @@ int pcm_softmax_ce(const float *logits, const int64_t *targets,
                    int32_t steps, int32_t batch,
                    int32_t vocab, float *loss, int64_t *argmax, float *dlogits,
                    float *scratch, int32_t *status, void *stream) {
+    PCM_API_GUARD;
     PCM_REQUIRE(logits && targets && loss && scratch, PCM_EINVAL,
                 "softmax_ce: null pointer");
     PCM_REQUIRE(steps > 0 && batch > 0 && vocab > 0, PCM_EINVAL,
@@ -819,6 +820,7 @@ int pcm_output_ce(const float *x, int64_t ldx, const float *w,
                   int32_t steps, int32_t batch, int32_t vocab, int32_t hidden,
                   float *logits, float *loss, int64_t *argmax, float *dlogits,
                   float *scratch, int32_t *status, void *stream) {
+    PCM_API_GUARD;
     PCM_REQUIRE(x && w && bias && targets && loss && scratch, PCM_EINVAL,
                 "output_ce: null pointer");
     PCM_REQUIRE(steps > 0 && batch > 0 && vocab > 0 && hidden > 0, PCM_EINVAL,
@@ -881,6 +883,7 @@ int pcm_softmax_ce_static(const float *logits, const int64_t *targets,
                           int32_t steps, int32_t batch, int32_t vocab,
                           float *loss, int64_t *argmax, float *dlogits,
                           int32_t *status, void *stream) {
+    PCM_API_GUARD;
     PCM_REQUIRE(logits && targets && loss, PCM_EINVAL,
                 "softmax_ce_static: null pointer");
     PCM_REQUIRE(steps > 0 && batch > 0 && vocab > 0, PCM_EINVAL,
@@ -902,6 +905,7 @@ int pcm_softmax_ce_static(const float *logits, const int64_t *targets,
 int pcm_search_step(const float *logits, int64_t rows, int32_t vocab,
                     int32_t search, float temperature, uint64_t seed,
                     int32_t step, int64_t *tokens_out, void *stream) {
+    PCM_API_GUARD;
     PCM_REQUIRE(logits && tokens_out && rows > 0 && vocab > 0, PCM_EINVAL,
                 "search_step: bad args");
     PCM_REQUIRE(rows < (1ll << 31), PCM_EINVAL, "search_step: too many rows");
@@ -916,6 +920,7 @@ int pcm_search_step(const float *logits, int64_t rows, int32_t vocab,
 
 int pcm_reparam_forward(const float *mu, const float *logvar, const float *eps,
                         float *z, int64_t n, void *stream) {
+    PCM_API_GUARD;
     PCM_REQUIRE(mu && logvar && eps && z && n > 0, PCM_EINVAL,
                 "reparam_forward: bad args");
     hipLaunchKernelGGL(reparam_fwd_kernel, dim3(grid_for(n)), dim3(256), 0,
@@ -926,6 +931,7 @@ int pcm_reparam_forward(const float *mu, const float *logvar, const float *eps,
 int pcm_reparam_backward(const float *dz, const float *logvar,
                          const float *eps, float *dmu, float *dlogvar,
                          int64_t n, void *stream) {
+    PCM_API_GUARD;
     PCM_REQUIRE(dz && logvar && eps && n > 0, PCM_EINVAL,
                 "reparam_backward: bad args");
     hipLaunchKernelGGL(reparam_bwd_kernel, dim3(grid_for(n)), dim3(256), 0,
@@ -940,6 +946,7 @@ size_t pcm_kl_scratch_floats(int64_t n) {
 
 int pcm_kl_forward(const float *mu, const float *logvar, float *kl,
                    float *scratch, int64_t n, void *stream) {
+    PCM_API_GUARD;
     PCM_REQUIRE(mu && logvar && kl && scratch && n > 0, PCM_EINVAL,
                 "kl_forward: bad args");
     const int parts = (int)pcm_kl_scratch_floats(n);
@@ -953,6 +960,7 @@ int pcm_kl_forward(const float *mu, const float *logvar, float *kl,
 
 int pcm_kl_backward(const float *dkl, const float *mu, const float *logvar,
                     float *dmu, float *dlogvar, int64_t n, void *stream) {
+    PCM_API_GUARD;
     PCM_REQUIRE(dkl && mu && logvar && n > 0, PCM_EINVAL,
                 "kl_backward: bad args");
     hipLaunchKernelGGL(kl_bwd_kernel, dim3(grid_for(n)), dim3(256), 0,
@@ -967,6 +975,7 @@ int pcm_prepare_batch(const int64_t *flat, const int64_t *offsets,
                       uint64_t seed, const uint8_t *keep_mask,
                       int64_t dropout_index, int64_t *enc, int64_t *dec,
                       int64_t *tgt, void *stream) {
+    PCM_API_GUARD;
     PCM_REQUIRE(flat && offsets && enc && dec && tgt, PCM_EINVAL,
                 "prepare_batch: null pointer");
     PCM_REQUIRE(batch > 0 && steps > 0, PCM_EINVAL,
@@ -985,6 +994,7 @@ int pcm_adam_step(float *param, const float *grad, float *exp_avg,
                   float *exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, int64_t step, float grad_scale,
                   void *stream) {
+    PCM_API_GUARD;
     PCM_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1,
                 PCM_EINVAL, "adam_step: bad args");
     const double bc1 = 1.0 - pow((double)beta1, (double)step);

@@ -292,14 +292,19 @@ _scratch_cache = {}
 
 
 def _linear_scratch(dev, m, n, k):
-    """One reusable scratch buffer per device (calls on a stream are ordered;
-    the buffer is only used inside a single library call)."""
+    """One reusable scratch buffer per (device, stream): calls on a stream are
+    ordered and the buffer is only used inside a single library call; two
+    streams (two host threads, or the two directions of a bidirectional
+    encoder) must not share one."""
     lib = load()
     need = lib.pcm_linear_scratch_bytes(m, n, k)
-    buf = _scratch_cache.get(dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _scratch_cache.get(key)
     if buf is None or buf.numel() * 4 < need:
+        if len(_scratch_cache) >= 16:   # streams come and go: do not hoard
+            _scratch_cache.clear()
         buf = torch.empty(need // 4 + 1, dtype=torch.float32, device=dev)
-        _scratch_cache[dev] = buf
+        _scratch_cache[key] = buf
     return buf
 
 

@@ -365,6 +365,78 @@ def test_pipelined_loops_keep_generated_inputs_alive():
         list(P.encode_batches(vae, [host[0].to(dev)], streams=2))
 
 
+def test_host_threads_share_the_library():
+    """the library's process-wide state (launch probe,
+    precision switch, side streams, lazily set kernel attributes) is guarded by
+    one host-side lock, so several host threads may enter at once -- each with
+    its own model and its own HIP stream here, as a serving process would, and
+    forward + backward both (autograd runs backward on its device thread
+    anyway).  Results equal the serial ones bit for bit."""
+    import threading
+    import paccmann_chemistry_amd as P
+    from paccmann_chemistry_amd import vae_loss_function
+    from oracle import weights as W
+    p = {
+        'latent_dim': 16, 'rnn_cell_size': 64, 'embedding_size': 20,
+        'vocab_size': 20, 'stack_width': 6, 'stack_depth': 5, 'n_layers': 2,
+        'dropout': 0.0, 'batch_size': 24, 'batch_mode': 'padded',
+        'embedding': 'one_hot', 'use_stack': True, 'bidirectional': False
+    }
+    dev = _dev()
+    n_threads, rounds, steps = 4, 6, 11
+    sd = W.make_state_dict(p, 5300)
+    jobs = []
+    for k in range(n_threads):
+        tokens = W.synthetic_tokens(steps, 24, 20, 5301 + k).to(dev)
+        eps = torch.from_numpy(np.random.default_rng(5310 + k).standard_normal(
+            (24, 16)).astype(np.float32)).to(dev)
+        jobs.append((tokens, W.shifted_targets(tokens.cpu()).to(dev), eps))
+
+    def one(vae, job):
+        tokens, targets, eps = job
+        vae.zero_grad()
+        dec_loss, mu, logvar = vae(tokens, tokens, targets, eps=eps)
+        total, _ = vae_loss_function(dec_loss, mu, logvar, kl_growth=0.003,
+                                     step=4000)
+        total.backward()
+        grads = torch.cat([q.grad.reshape(-1) for q in vae.parameters()
+                           if q.grad is not None])
+        return total.detach().clone(), grads.clone()
+
+    models = [_build_vae(p, sd) for _ in range(n_threads)]
+    serial = [one(models[k], jobs[k]) for k in range(n_threads)]
+    torch.cuda.synchronize()
+    results = [[] for _ in range(n_threads)]
+    errors = []
+    start = threading.Barrier(n_threads)
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream(dev)
+            start.wait()
+            with torch.cuda.stream(stream):
+                for _ in range(rounds):
+                    results[k].append(one(models[k], jobs[k]))
+            stream.synchronize()
+        except Exception as exc:   # noqa: BLE001 (reported below)
+            errors.append((k, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(k, ))
+               for k in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for k in range(n_threads):
+        assert len(results[k]) == rounds
+        for loss, grads in results[k]:
+            assert torch.equal(loss, serial[k][0])
+            assert torch.equal(grads, serial[k][1])
+        models[k].check_tokens()
+
+
 def test_determinism_bitwise():
     """Same inputs twice => bitwise identical loss and gradients."""
     g = Golden('vae_odd_padded')

@@ -5,4 +5,6 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/prof_$tag
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o r --output-format csv -- python3 bench.py "$@" > gpurun_out/prof_$tag.log 2>&1
-echo exit=$?; tail -1 gpurun_out/prof_$tag.log
+echo exit=$?; tail -1 gpurun_out/prof_$tag.log | cut -c1-400
+# the per-dispatch trace is large (gpurun merges at most 64 MiB back): keep the stats
+rm -f gpurun_out/prof_$tag/r_kernel_trace.csv
