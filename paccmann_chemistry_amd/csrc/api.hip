@@ -247,10 +247,9 @@ int pcm_sg_layout(const pcm_dims *d, int steps, int training, int dropout,
         take(off, o->use_stack ? (size_t)o->B * (o->Hn / 16) * 64 : 0);
     o->off_cpre = take(off, persist ? (size_t)steps * o->B * 64 : 0);
     {
-        size_t hf = 0, xdf = 0, xtf = 0, wf = 0, cp = 0;
+        size_t hf = 0, xdf = 0, xtf = 0, wf = 0;
         if (persist && pcm_persist_fwd_mode() == 2)
-            pcm_persist2_fwd_regions(o->B, steps, &hf, &xdf, &xtf, &wf, &cp);
-        o->off_cpart = take(off, cp);
+            pcm_persist2_fwd_regions(o->B, steps, &hf, &xdf, &xtf, &wf);
         o->off_hfrag[0] = take(off, hf);
         o->off_hfrag[1] = take(off, hf);
         o->off_xdfrag = take(off, o->dropout ? xdf : 0);

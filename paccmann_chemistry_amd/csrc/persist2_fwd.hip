@@ -57,9 +57,8 @@ constexpr int KP0 = 64 + PH;     // packed K of layer 0: stack top, h0
 constexpr int KP1 = 2 * PH;      // packed K of layer 1: h0 (input), h1
 constexpr int PARK_FLOATS = 4 * 3 * PROWS * PCOLS;   // [wave][gate][row][unit]
 constexpr int HID_FLOATS = 3 * PROWS * PCOLS;        // [gate][row][unit]
-constexpr int CW_FLOATS = 64 * PCOLS;     // the block's [64 outputs][16 units] of [Wc ; Ws]
-constexpr int CRED_FLOATS = PROWS * PCOLS;   // the block's tile of a new h1, [row][unit]
-constexpr int CPART_ROW_FLOATS = PMEM * 64;   // control partials of one batch row
+constexpr int CW_FLOATS = 4 * PHC * 2 * 16;          // [wave][chunk][o][g][4]
+constexpr int CRED_FLOATS = 4 * PROWS * 2;
 constexpr int SYNC_WORDS = 32;
 // Hand-off tiles are stored fragment-major, the order the MFMA operand loads
 // take them in: [row tile][chunk][k slice (= consumer wave)][lane][4 floats], so
@@ -193,7 +192,7 @@ struct Persist2Args {
     float *S;              // training: [(T+1)][B][DW], else [2][B][DW]
     float *av;             // training: [T][B][AVW], else [B][AVW]
     float *xtop;           // [T][B][PWP]
-    float *cpart;          // [T][B][32 blocks][64] partial stack control / push sums
+    float *cpre;           // [T][B][64] stack control / push pre-activations
     float *hf[2];          // [(T+1)][groups][FRAG_GROUP_FLOATS] fragment-major h
     float *xdf;            // [T][groups][FRAG_GROUP_FLOATS] dropped h0, or null
     float *xtf;            // [T][groups][XFRAG_GROUP_FLOATS] fragment-major stack tops
@@ -471,61 +470,15 @@ __device__ __forceinline__ void cell_lazy_stores(const Persist2Args &A, int xt,
     }
 }
 
-// ---- stack-control partial sums (role X) ----------------------------------------------
-// The 3 + W control / push pre-activations of a row are dot products over all
-// 512 units of h1; every block contributes the part of ITS 16 units for the 64
-// rows of the group, [64 x 16] . [16 x 64] on sixteen MFMAs per wave, the moment
-// it has computed those units -- so nobody has to sweep the whole of h1 again
-// for them (the first persistent kernel, and this one at first, did: 8.5 us of
-// the critical chain per step).  The owner of a stack row sums the 32 partials
-// in block order.  h: this thread's four new units of row xs / 4.
-__device__ __forceinline__ bool publish_ctrl_partials(
-    const Persist2Args &A, Role &R, float *hbuf, float *tile, f32x4 cwB, f32x4 h,
-    int xs, int lane, int row0, int nrows, int ci, int slot) {
-    const int row = xs >> 2, q = xs & 3;
-    const int r16 = lane & 15, g = lane >> 4;
-    *(f32x4 *)(hbuf + row * PCOLS + 4 * q) = h;
-    if (!role_barrier(R)) return false;   // (also: every gate-math read of `tile` is done)
-    f32x4 acc[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const f32x4 a = *(const f32x4 *)(hbuf + (16 * mt + r16) * PCOLS + 4 * g);
-        acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], cwB[ks], acc[mt], 0,
-                                                           0, 0);
-    }
-    // [row][output] through LDS, so that a thread stores 64 consecutive bytes
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            tile[(16 * mt + 4 * g + e) * 64 + 16 * R.w + r16] = acc[mt][e];
-    if (!role_barrier(R)) return false;
-    if (row < nrows) {
-        const i32x4s rs = make_rsrc(
-            A.cpart + (size_t)slot * A.B * CPART_ROW_FLOATS,
-            (unsigned)A.B * CPART_ROW_FLOATS * 4);
-        const unsigned vo =
-            (unsigned)((((row0 + row) * PMEM + ci) * 64 + 16 * q) * 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            store_sc1(*(const f32x4 *)(tile + row * 64 + 16 * q + 4 * i), rs, vo,
-                      16u * i);
-    }
-    return true;
-}
-
 // ---- role X: the critical chain --------------------------------------------------------
 __device__ __forceinline__ void role_x(const Persist2Args &A, float *lds,
                                        unsigned *sw, int xt) {
     const int DWp = (A.DW + 3) & ~3;
     float *xpark = lds;
     float *hid = lds + 2 * PARK_FLOATS;              // [2 layers][3][PROWS][PCOLS]
-    float *cwp = hid + 2 * HID_FLOATS;               // [64 outputs][PCOLS]
-    float *hbuf = cwp + CW_FLOATS;                   // [PROWS][PCOLS]
-    float *bias = hbuf + CRED_FLOATS;                // [2 layers][4][PCOLS]
+    float *cwlds = hid + 2 * HID_FLOATS;
+    float *cred = cwlds + CW_FLOATS;
+    float *bias = cred + CRED_FLOATS;                // [2 layers][4][PCOLS]
     float *cu = bias + 2 * 4 * PCOLS;                // [2][64]
     float *Sbuf = cu + 2 * 64 + SYNC_WORDS;          // [2 rows][DWp]
     const int lane = xt & 63;
@@ -540,6 +493,7 @@ __device__ __forceinline__ void role_x(const Persist2Args &A, float *lds,
     const int nrows = min(PROWS, A.B - grow0);
     const int j0 = ci * PCOLS;
     const int r16 = lane & 15, g = lane >> 4;
+    gu32 *cnt_c = (gu32 *)(A.sync + (group * 4 + 0) * SYNC_STRIDE);
     gu32 *cnt_x = (gu32 *)(A.sync + (group * 4 + 1) * SYNC_STRIDE);
     gu32 *cnt_0 = (gu32 *)(A.sync + (group * 4 + 2) * SYNC_STRIDE);
     gu32 *cnt_1 = (gu32 *)(A.sync + (group * 4 + 3) * SYNC_STRIDE);
@@ -561,16 +515,19 @@ __device__ __forceinline__ void role_x(const Persist2Args &A, float *lds,
         for (int gate = 0; gate < 3; ++gate)
             w1x[c][gate] = *(const f32x4 *)(A.wpack[1] +
                 (size_t)(gate * PH + j0 + r16) * KP1 + 64 * c + 16 * wave + 4 * g);
-    // the block's columns of [Wc ; Ws] -> LDS: [output][unit], zero past 3 + W
+    // the block's two stack control / push rows (outputs 2 ci, 2 ci + 1) -> LDS,
+    // laid out as the lanes of each wave consume them: [wave][chunk][o][g][4]
     for (int idx = xt; idx < CW_FLOATS; idx += RTHREADS) {
-        const int out = idx / PCOLS, u = idx - out * PCOLS;
+        const int e = idx & 3, gg = (idx >> 2) & 3, o = (idx >> 4) & 1;
+        const int c = (idx >> 5) % PHC, wv = idx / (PHC * 32);
+        const int out = 2 * ci + o;
         float v = 0.f;
         if (out < NO) {
             const float *wrow = out < 3 ? A.ctrl_w + (size_t)out * PH
                                         : A.push_w + (size_t)(out - 3) * PH;
-            v = wrow[j0 + u];
+            v = wrow[64 * c + 16 * wv + 4 * gg + e];
         }
-        cwp[idx] = v;
+        cwlds[idx] = v;
     }
     for (int idx = xt; idx < 2 * 4 * PCOLS; idx += RTHREADS) {
         const int l = idx / (4 * PCOLS), rem = idx - l * 4 * PCOLS;
@@ -589,19 +546,13 @@ __device__ __forceinline__ void role_x(const Persist2Args &A, float *lds,
     f32x4 hp1 = *(const f32x4 *)(A.hs[1] + (size_t)eb * PH + j0 + 4 * eq);
     long long tk_next = A.tokens[eb];                 // token of step 0
     if (!role_barrier(R)) return;
-    // this wave's B fragment of the control product: outputs 16 wave + (lane & 15)
-    const f32x4 cwB = *(const f32x4 *)(cwp + (16 * wave + r16) * PCOLS + 4 * g);
-    // control partials of the INITIAL top-layer state (slot 0); the arrive is the
-    // first on the h1 counter: step t waits for (t + 1) x 32
-    if (!publish_ctrl_partials(A, R, hbuf, xpark, cwB, hp1, xt, lane, grow0, nrows,
-                               ci, 0))
-        return;
-    if (!role_arrive(R, cnt_1)) return;
 
     // fragment-major tiles: this wave's k slice, this lane
     const unsigned voff_h = (unsigned)((wave * 64 + lane) * 16);
     const unsigned voff_x = voff_h;
     const unsigned slab_h = FRAG_GROUP_FLOATS * 4, slab_x = XFRAG_GROUP_FLOATS * 4;
+    const unsigned slab_c = (unsigned)A.B * 64 * 4;
+    const float *cwl = cwlds + wave * (PHC * 32) + g * 4;
     const int W = A.W, D = A.D, DW = A.DW, AVW = A.AVW;
     const float inv_W = 1.0f / (float)W;
     const int nq = (DW + 3) >> 2;
@@ -618,6 +569,7 @@ __device__ __forceinline__ void role_x(const Persist2Args &A, float *lds,
         const i32x4s rs_h1n =
             make_rsrc(A.hf[1] + (gslot + A.groups) * FRAG_GROUP_FLOATS, slab_h);
         const i32x4s rs_xt = make_rsrc(A.xtf + gslot * XFRAG_GROUP_FLOATS, slab_x);
+        const i32x4s rs_cp = make_rsrc(A.cpre + (size_t)t * A.B * 64, slab_c);
         const i32x4s rs_xd = make_rsrc(
             A.xdf ? A.xdf + gslot * FRAG_GROUP_FLOATS : A.hf[0], slab_h);
         const unsigned target = (unsigned)(t + 1) * PMEM;
@@ -628,38 +580,87 @@ __device__ __forceinline__ void role_x(const Persist2Args &A, float *lds,
         int xs = xt;
         asm volatile("" : "+v"(xs));
 
-        // ---- X1 / X3: the stack step of this block's two rows --------------------------
-        // (h1_{t-1} and its control partials have been published)
-        if (!role_wait(R, cnt_1, target, error)) return;
+        // ---- X1 / X2: stack control products of the block's two outputs --------------
+        if (t > 0 && !role_wait(R, cnt_1, (unsigned)t * PMEM, error)) return;
         STAMP(0);
         {
-            // 32 partials x 64 outputs per row: 4 x 16 B per thread, into LDS
-            const int r = xs >> 7, c = (xs >> 2) & 31, q = xs & 3;
-            if (r < snrows) {
-                const i32x4s rs = make_rsrc(
-                    A.cpart + (size_t)t * A.B * CPART_ROW_FLOATS,
-                    (unsigned)A.B * CPART_ROW_FLOATS * 4);
-                const unsigned vo =
-                    (unsigned)((((srow0 + r) * PMEM + c) * 64 + 16 * q) * 4);
-                f32x4 v[4];
+            float cdot[4][2] = {};
+            f32x4 a[2][4];
+            // (read per step: hoisted out of the loop, the sixteen weight
+            // fragments would sit in registers for the whole sequence)
+            const float *cwl_t = cwl;
+            asm volatile("" : "+v"(cwl_t));
+            chunk_load(a[0], rs_h1p, voff_h, 0, FRAG_ROWTILE_BYTES);
+            chunk_load(a[1], rs_h1p, voff_h, FRAG_CHUNK_BYTES, FRAG_ROWTILE_BYTES);
+            // a rolled loop over chunk pairs: fully unrolled, hipcc issues all
+            // 32 fragment loads up front (128 registers)
+#pragma unroll 1
+            for (int c = 0; c < PHC; c += 2) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = load_sc1(rs, vo, 16u * i);
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 cur[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    *(f32x4 *)(xpark + (r * PMEM + c) * 64 + 16 * q + 4 * i) = v[i];
+                    for (int mt = 0; mt < 4; ++mt) cur[mt] = a[h][mt];
+                    if (c + h + 2 < PHC)
+                        chunk_load(a[h], rs_h1p, voff_h,
+                                   (c + h + 2) * FRAG_CHUNK_BYTES,
+                                   FRAG_ROWTILE_BYTES);
+#pragma unroll
+                    for (int o = 0; o < 2; ++o) {
+                        const f32x4 cwv =
+                            *(const f32x4 *)(cwl_t + ((c + h) * 2 + o) * 16);
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                cdot[mt][o] = fmaf(cur[mt][e], cwv[e], cdot[mt][o]);
+                    }
+                }
             }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    float v = cdot[mt][o];
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if (g == 0) cred[(wave * PROWS + 16 * mt + r16) * 2 + o] = v;
+                }
         }
         if (!role_barrier(R)) return;
-        STAMP(1);
-        if (xs < 2 * 64 && (xs >> 6) < snrows) {
-            const int r = xs >> 6, o = xs & 63;
-            float sum = 0.f;
-#pragma unroll 8
-            for (int c = 0; c < PMEM; ++c) sum += xpark[(r * PMEM + c) * 64 + o];
-            const float bb = o < 3 ? A.ctrl_b[o] : (o < NO ? A.push_b[o - 3] : 0.f);
-            cu[64 * r + o] = o < 3 ? sum + bb : tanhf(sum + bb);
+        if (xt < PROWS) {
+            float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                c0 += cred[(w * PROWS + xt) * 2 + 0];
+                c1 += cred[(w * PROWS + xt) * 2 + 1];
+            }
+            u32x2 pair = {__float_as_uint(c0), __float_as_uint(c1)};
+            if (xt < nrows)
+                __builtin_amdgcn_raw_buffer_store_b64(
+                    pair, rs_cp, (unsigned)(((grow0 + xt) * 64 + 2 * ci) * 4), 0, SC1);
         }
+        if (!role_arrive(R, cnt_c)) return;
+        STAMP(1);
+
+        // ---- X3: the stack step of this block's two rows ------------------------------
+        if (!role_wait(R, cnt_c, target, error)) return;
         STAMP(2);
+        if (snrows > 0) {
+            if (xs < 32) {
+                const int r = xs >> 4, q4 = xs & 15;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (r < snrows)
+                    v = load_sc1(rs_cp, (unsigned)(((srow0 + r) * 64 + 4 * q4) * 4), 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int o = 4 * q4 + e;
+                    const float bb = o < 3 ? A.ctrl_b[o]
+                                           : (o < NO ? A.push_b[o - 3] : 0.f);
+                    cu[64 * r + o] = o < 3 ? v[e] + bb : tanhf(v[e] + bb);
+                }
+            }
+        }
         if (!role_barrier(R)) return;
         if (snrows > 0 && xs < 2) {
             float *c = cu + 64 * xs;
@@ -834,11 +835,6 @@ __device__ __forceinline__ void role_x(const Persist2Args &A, float *lds,
             CellOut co;
             cell_epilogue(A, xpark, hid + HID_FLOATS, bias + 4 * PCOLS, hp1, xs, 1, t,
                           grow0, nrows, ci, zero, zero, zero, rs_h1n, rs_xd, co);
-            // ... and this block's share of the next step's stack controls
-            if (t + 1 < A.T &&
-                !publish_ctrl_partials(A, R, hbuf, xpark, cwB, hp1, xs, lane, grow0,
-                                       nrows, ci, t + 1))
-                return;
             if (!role_arrive(R, cnt_1)) return;
             cell_lazy_stores(A, xs, 1, t, grow0, nrows, ci, co);
         }
@@ -912,7 +908,7 @@ __device__ __forceinline__ void role_y(const Persist2Args &A, float *lds,
     }
     for (int t = 0; t < A.T; ++t) {
         // ---- Y1: h1_{t-1} . W_hh1 -> hid1 of step t -------------------------------------
-        if (t > 0 && !role_wait(R, cnt_1, (unsigned)(t + 1) * PMEM, error)) return;
+        if (t > 0 && !role_wait(R, cnt_1, (unsigned)t * PMEM, error)) return;
         STAMP(0);
         {
             const i32x4s rs = make_rsrc(
@@ -994,8 +990,7 @@ __global__ void persist2_report_kernel(const unsigned *error, int32_t *status) {
 // ---- host side ----------------------------------------------------------------------------
 // floats of the fragment-major regions for `steps` steps of a batch of B rows
 void pcm_persist2_fwd_regions(int B, int steps, size_t *hfrag, size_t *xdfrag,
-                              size_t *xtfrag, size_t *wfrag, size_t *cpart) {
-    *cpart = (size_t)steps * B * CPART_ROW_FLOATS;
+                              size_t *xtfrag, size_t *wfrag) {
     const size_t groups = (size_t)(B + PROWS - 1) / PROWS;
     *hfrag = (size_t)(steps + 1) * groups * FRAG_GROUP_FLOATS;
     *xdfrag = (size_t)steps * groups * FRAG_GROUP_FLOATS;
@@ -1025,7 +1020,7 @@ int pcm_launch_persist2_fwd(const SGLayout &lay, float *sv,
     }
     a.xdrop = lay.dropout ? sv + lay.off_xdrop[1] : nullptr;
     a.S = sv + lay.off_S; a.av = sv + lay.off_av; a.xtop = sv + lay.off_xtop;
-    a.cpart = sv + lay.off_cpart;
+    a.cpre = sv + lay.off_cpre;
     a.groups = (lay.B + PROWS - 1) / PROWS;
     a.hf[0] = sv + lay.off_hfrag[0]; a.hf[1] = sv + lay.off_hfrag[1];
     a.xdf = lay.dropout ? sv + lay.off_xdfrag : nullptr;
@@ -1075,7 +1070,7 @@ int pcm_launch_persist2_fwd(const SGLayout &lay, float *sv,
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
         static const char *xname[11] = {
-            "X wait h1", "X control partials -> LDS", "X sum partials",
+            "X wait h1", "X ctrl sweep + publish + arrive c", "X wait c",
             "X stack step + arrive x", "X wait x (+ token gates)",
             "X l0 x product + park + wait hid0", "X l0 gate math + arrive 0",
             "X wait h0", "X l1 x product", "X park + wait hid1",

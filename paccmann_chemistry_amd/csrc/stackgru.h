@@ -32,7 +32,7 @@ struct SGLayout {
     // role-split persistent kernel (persist2_fwd.hip) only: hand-off tiles in
     // fragment-major order (hidden states of both layers, dropped layer-1 input,
     // stack tops) and W_hh1 packed in consumption order; 0 floats otherwise
-    size_t off_hfrag[2], off_xdfrag, off_xtfrag, off_wfrag, off_cpart;
+    size_t off_hfrag[2], off_xdfrag, off_xtfrag, off_wfrag;
     size_t off_tokg;   // V x 3*Hn   token gate table (b_ih0 folded in)
     size_t off_wpack[PCM_MAX_LAYERS];  // 3*Hn x Kp[l]
     size_t off_bpack[PCM_MAX_LAYERS];  // 4*Hn
@@ -160,7 +160,7 @@ int pcm_persist_fwd_mode();
 // persist2_fwd.hip: the role-split persistent kernel (same workspace regions)
 bool pcm_persist2_fwd_shape_ok(const SGLayout &lay);
 void pcm_persist2_fwd_regions(int B, int steps, size_t *hfrag, size_t *xdfrag,
-                              size_t *xtfrag, size_t *wfrag, size_t *cpart);
+                              size_t *xtfrag, size_t *wfrag);
 int pcm_launch_persist2_fwd(const SGLayout &lay, float *sv,
                             const pcm_stackgru_params *w, const int64_t *tokens,
                             float dropout_p, uint64_t seed, int32_t *status,
