@@ -171,11 +171,26 @@ def probe_families(p, batch, seq_len):
     # columns, of which width + vocabulary carry gradient)
     dw = (2 * 3 * hid * hid + (layers - 1) * 2 * 3 * hid * 2 * hid
           + 2 * 3 * hid * 128) * batch * seq_len
+    # Round 3: with two or more layers the bulk of the stack adjoint (the
+    # 3*D*W*4 bytes per row) rides as extra blocks in layer 0's reverse-cell
+    # launch, and the launch left on the chain carries the stack-top terms and
+    # the gate gradient only (PCM_STACK_SPLIT=0: the fused launch as before)
+    split = (layers > 1 and os.environ.get('PCM_STACK_SPLIT', '1') != '0'
+             and width <= 61)
+    if split:
+        stack_name = ('stack_bwd_finish_kernel (stack-top terms + top-layer gate '
+                      'gradient; the bulk adjoint rides in the layer-0 cell launch)')
+        stack_bwd = (9 * hid * 4 + 6 * width * 4) * batch
+        cell0_name = ('gru_cell_bwd_kernel (layer 0, + the bulk stack adjoint as '
+                      'rider blocks: 3*D*W*4 bytes per row, not priced)')
+    else:
+        stack_name = 'stack_bwd_kernel (+ top-layer gate gradient)'
+        cell0_name = 'gru_cell_bwd_kernel (layer 0)'
     fams = [
         (11, 'gru_cell_fwd_kernel (layer 0)', 'mfma', l0),
         (2, 'stack_step_fwd_kernel', 'hbm', stack_fwd),
-        (51, 'gru_cell_bwd_kernel (layer 0)', 'mfma', l0),
-        (4, 'stack_bwd_kernel (+ top-layer gate gradient)', 'hbm', stack_bwd),
+        (51, cell0_name, 'mfma', l0),
+        (4, stack_name, 'hbm', stack_bwd),
         (6, 'gemm_tn_kernel<0> (dW_hh, dW_ih of one StackGRU)', 'mfma', dw),
     ]
     if layers > 1:

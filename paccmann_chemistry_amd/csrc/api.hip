@@ -281,6 +281,7 @@ int pcm_sg_scratch(const SGLayout &lay, SGScratch *o) {
         take(off, (size_t)lay.T * lay.B * (lay.V > 128 ? lay.V : 128));
     o->off_dtokg = take(off, (size_t)lay.V * 3 * lay.H);
     o->off_tmp = take(off, (size_t)lay.B * lay.Hp);
+    o->off_psum = take(off, (size_t)lay.B * 4);
     o->off_dwx = take(off, (size_t)3 * lay.H * (lay.Wp > 128 ? lay.Wp : 128));
     o->off_dcw = take(off, (size_t)(lay.AVW > 0 ? lay.AVW : 4) * (lay.H + 1));
     for (int l = 0; l < lay.L; ++l)
@@ -860,6 +861,17 @@ int pcm_stackgru_backward(const pcm_dims *dims,
     }
     float *dtop = scf + sc.off_dtop;
     float *tmp = scf + sc.off_tmp;
+    float *psum = scf + sc.off_psum;
+    // PCM_STACK_SPLIT=0: the whole stack adjoint in its own launch on the chain
+    // rows [0, Bt * top%) ride in the top layer's launch, the rest in layer 0's
+    static const int rider_top_percent = [] {
+        const char *e = getenv("PCM_STACK_RIDER_TOP");
+        return e ? std::max(0, std::min(100, atoi(e))) : 0;
+    }();
+    static const bool stack_split_on = [] {
+        const char *e = getenv("PCM_STACK_SPLIT");
+        return !e || atoi(e) != 0;
+    }();
     // fused reverse cell needs whole 64-wide chunks inside every gate segment
     const bool fused_bwd = (H % 64) == 0;
     if (fused_bwd) {
@@ -1204,6 +1216,7 @@ int pcm_stackgru_backward(const pcm_dims *dims,
         const int32_t *len = lengths ? lengths + b0 : nullptr;
         int &cur = cur_c[c];
         int dtop_parts = 1;
+        bool bulk_done = false;
         for (int l = L - 1; l >= 0 && Bt > 0; --l) {
             float *gates = sv + lay.off_gates[l] + (size_t)t * B * 4 * H + oG;
             float *dhl = dh + (size_t)l * B * Hp + oH;
@@ -1258,6 +1271,33 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                                    (size_t)t * lay.hs_step() + oH;
                 }
                 if (l == 0) dtop_parts = pcm_cell_bwd_xparts(cb);
+                // the bulk of this step's stack adjoint rides in the top
+                // layer's launch (it needs nothing the cells produce)
+                cb.rider_rows = 0; cb.ncell = 0;
+                memset(&cb.rider, 0, sizeof(cb.rider));
+                if ((l == L - 1 || l == 0) && L >= 2 && lay.use_stack &&
+                    stack_split_on && lay.W <= 61 && lay.AVW <= 64 &&
+                    (bulk_done || pcm_cell_bwd_takes_rider(cb, lay.D, lay.W))) {
+                    // (both launches of a step take the narrow fp32 tile or
+                    // neither does: the first decides)
+                    const int n_top = (int)((long long)Bt * rider_top_percent / 100);
+                    const int r0 = l == 0 ? n_top : 0;
+                    const int rn = l == 0 ? Bt - n_top : n_top;
+                    bulk_done = true;
+                    if (rn > 0) {
+                        const size_t oS = (size_t)(b0 + r0) * lay.DW;
+                        cb.rider_rows = rn;
+                        cb.rider.dS_next = dS[cur] + oS;
+                        cb.rider.dS_prev = dS[cur ^ 1] + oS;
+                        cb.rider.S_prev = sv + lay.s_index(t) + oS;
+                        cb.rider.av =
+                            sv + lay.av_index(t) + (size_t)(b0 + r0) * lay.AVW;
+                        cb.rider.psum = psum + (size_t)(b0 + r0) * 4;
+                        cb.rider.lengths = len ? len + r0 : nullptr;
+                        cb.rider.B = rn; cb.rider.D = lay.D; cb.rider.W = lay.W;
+                        cb.rider.AVW = lay.AVW; cb.rider.t = t;
+                    }
+                }
                 pcm_probe_begin(PCM_K_CELL_BWD, l);
                 pcm_launch_cell_bwd(cb, cst);
                 pcm_probe_end(PCM_K_CELL_BWD, l);
@@ -1337,8 +1377,10 @@ int pcm_stackgru_backward(const pcm_dims *dims,
                                     (size_t)(t - 1) * lay.hs_step() + oH
                               : nullptr;
             s.ctrl_w = weights->ctrl_w; s.push_w = weights->push_w;
+            s.psum = bulk_done ? psum + (size_t)b0 * 4 : nullptr;
             pcm_probe_begin(PCM_K_STACK_BWD);
-            rc = pcm_launch_stack_bwd(s, cst);
+            rc = bulk_done ? pcm_launch_stack_bwd_finish(s, cst)
+                           : pcm_launch_stack_bwd(s, cst);
             pcm_probe_end(PCM_K_STACK_BWD);
             if (rc) return rc;
             cur ^= 1;

@@ -251,6 +251,9 @@ __global__ __launch_bounds__(256, FIXED_MODE == 0 ? 3 : 2) void gemm_tn_kernel(G
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     float cs0 = 0.f, cs1 = 0.f;  // column sums of A (this lane's k parity)
+    // (wave-uniform) the first tile column's left waves hold every A column of the tile
+    const bool want_cs = (p.colsum1 || p.colsum2) && n0 == 0 &&
+                         (mode == 0 ? wn == 0 : (mode == 1 || wave == 0));
     if (c0 < c1) {
         // thread -> (k row, 4-wide column group) of the 16 x 128 operand chunks
         const int k_a = tid >> 5, q_a = tid & 31;  // + 8 rows for the second load
@@ -301,7 +304,11 @@ __global__ __launch_bounds__(256, FIXED_MODE == 0 ? 3 : 2) void gemm_tn_kernel(G
             *(f32x4 *)(&Bs[buf][lofs]) = qb[0];
             *(f32x4 *)(&Bs[buf][lofs + 8 * TN_LD]) = qb[1];
         };
-        auto compute = [&](int buf) {
+        // CS: this wave's column sums are used (first tile column, left waves).
+        // An fp32 MFMA and a vector add of the same SIMD do not overlap
+        // (tools/mfma_valu_overlap.hip): the other waves must not pay for them.
+        auto compute = [&](int buf, auto cs_tag) {
+            constexpr bool CS = decltype(cs_tag)::value;
             const float *as = &As[buf][lk * TN_LD + rbase + lrow];
             const float *bs = &Bs[buf][lk * TN_LD + cbase + lrow];
             if constexpr (BF16) {
@@ -310,8 +317,11 @@ __global__ __launch_bounds__(256, FIXED_MODE == 0 ? 3 : 2) void gemm_tn_kernel(G
                 for (int i = 0; i < 8; ++i) {
                     a0[i] = as[2 * i * TN_LD];
                     b0[i] = bs[2 * i * TN_LD];
-                    cs0 += a0[i];
-                    if (mode != 1) { a1[i] = as[2 * i * TN_LD + 32]; cs1 += a1[i]; }
+                    if (CS) cs0 += a0[i];
+                    if (mode != 1) {
+                        a1[i] = as[2 * i * TN_LD + 32];
+                        if (CS) cs1 += a1[i];
+                    }
                     if (mode != 2) b1[i] = bs[2 * i * TN_LD + 32];
                 }
                 const bf16x8 pa0 = __builtin_convertvector(a0, bf16x8);
@@ -334,7 +344,7 @@ __global__ __launch_bounds__(256, FIXED_MODE == 0 ? 3 : 2) void gemm_tn_kernel(G
                 for (int kk = 0; kk < BK; kk += 2) {
                     const float a0 = as[kk * TN_LD], a1 = as[kk * TN_LD + 32];
                     const float b0 = bs[kk * TN_LD], b1 = bs[kk * TN_LD + 32];
-                    cs0 += a0; cs1 += a1;
+                    if (CS) { cs0 += a0; cs1 += a1; }
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(256, FIXED_MODE == 0 ? 3 : 2) void gemm_tn_kernel(G
                 for (int kk = 0; kk < BK; kk += 2) {
                     const float a0 = as[kk * TN_LD];
                     const float b0 = bs[kk * TN_LD], b1 = bs[kk * TN_LD + 32];
-                    cs0 += a0;
+                    if (CS) cs0 += a0;
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
                 }
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(256, FIXED_MODE == 0 ? 3 : 2) void gemm_tn_kernel(G
                 for (int kk = 0; kk < BK; kk += 2) {
                     const float a0 = as[kk * TN_LD], a1 = as[kk * TN_LD + 32];
                     const float b0 = bs[kk * TN_LD];
-                    cs0 += a0; cs1 += a1;
+                    if (CS) { cs0 += a0; cs1 += a1; }
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
                     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
                 }
@@ -364,27 +374,29 @@ __global__ __launch_bounds__(256, FIXED_MODE == 0 ? 3 : 2) void gemm_tn_kernel(G
         load_chunk(c0 + 1, ra[1], rb[1]);
         // pairs of chunks so the register sets alternate without copies; the
         // loads are unconditional, hence exact vmcnt waits
-        int c = c0;
-        for (; c + 1 < c1; c += 2) {
-            store_chunk(0, ra[0], rb[0]);
-            load_chunk(c + 2, ra[0], rb[0]);
-            __syncthreads();
-            compute(0);
-            store_chunk(1, ra[1], rb[1]);
-            load_chunk(c + 3, ra[1], rb[1]);
-            __syncthreads();
-            compute(1);
-        }
-        if (c < c1) {
-            store_chunk(0, ra[0], rb[0]);
-            __syncthreads();
-            compute(0);
-        }
+        auto k_loop = [&](auto cs_tag) {
+            int c = c0;
+            for (; c + 1 < c1; c += 2) {
+                store_chunk(0, ra[0], rb[0]);
+                load_chunk(c + 2, ra[0], rb[0]);
+                __syncthreads();
+                compute(0, cs_tag);
+                store_chunk(1, ra[1], rb[1]);
+                load_chunk(c + 3, ra[1], rb[1]);
+                __syncthreads();
+                compute(1, cs_tag);
+            }
+            if (c < c1) {
+                store_chunk(0, ra[0], rb[0]);
+                __syncthreads();
+                compute(0, cs_tag);
+            }
+        };
+        if (want_cs) k_loop(std::true_type{});
+        else k_loop(std::false_type{});
     }
 
-    if ((p.colsum1 || p.colsum2) && n0 == 0 &&
-        (mode == 0 ? wn == 0 : (mode == 1 || wave == 0))) {
-        // the first tile column's left waves hold every A column of the tile
+    if (want_cs) {
         cs0 += __shfl_xor(cs0, 32);
         cs1 += __shfl_xor(cs1, 32);
         if (lk == 0) {

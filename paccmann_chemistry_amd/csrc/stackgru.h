@@ -61,6 +61,7 @@ struct SGScratch {
     size_t off_onehot;  // T*B x V  one-hot of the input tokens
     size_t off_dtokg;   // V x 3H   gradient of the token gate table
     size_t off_tmp;     // B x Hp   scratch product (generic reverse path)
+    size_t off_psum;    // B x 4    control sums of the bulk stack adjoint (StackBulkArgs)
     size_t off_dwx;     // 3H x Wp  gradient of W_ih0's stack-top columns (padded)
     size_t off_dcw;     // AVW x H  gradient of [ctrl_w ; push_w] (padded rows)
     size_t off_wpackT[PCM_MAX_LAYERS];  // (H + Kxp) x 3H transposed weights
@@ -205,6 +206,22 @@ int pcm_launch_gate_bwd(const GateBwdArgs &a, hipStream_t stream);
 //   dx       = [dr,dz,dni] . W_ih[:, x-part]     (columns H.. ) which is added,
 //              dropout-masked, to dh[l-1] (l > 0) or stored as dtop (l == 0)
 // from K-contiguous transposed weights wpackT[(n), 3H].
+// Bulk part of the stack adjoint of a step: everything that does not depend on
+// the stack-top gradient the layer-0 reverse cell is about to produce (the
+// elementwise adjoint over all D*W elements and the three control sums, 30 KB of
+// traffic per row).  It rides in the TOP layer's reverse-cell launch of the same
+// step as extra blocks, off the critical chain; stack_bwd_finish_kernel adds the
+// stack-top terms (rows 0 and 1 of dL/dS_{t-1}, three W-long dot products).
+struct StackBulkArgs {
+    const float *dS_next; // [B, D*W] dL/dS'_t without the stack-top gradient
+    float *dS_prev;       // [B, D*W] dL/dS_{t-1}, complete except for that gradient
+    const float *S_prev;  // [B, D*W]
+    const float *av;      // [B, AVW] a, v of step t
+    float *psum;          // [B, 4] control sums (push, pop, no-op) of the bulk
+    const int32_t *lengths;
+    int B, D, W, AVW, t;
+};
+
 struct CellBwdArgs {
     const float *dgates;  // [B, 4H]  dr, dz, dni, dnh
     const float *wpackT;  // [H + Kxp, 3H]
@@ -224,8 +241,15 @@ struct CellBwdArgs {
     float *gates_low;        // [B, 4H] in: r,z,n,ghn ; out: dr,dz,dni,dnh (nullable)
     const float *hprev_low;  // [B, Hp]
     const int32_t *lengths;
+    // rider_rows > 0: that many extra blocks (one per batch row) behind the
+    // cell's own tiles run the bulk stack adjoint (ncell is set by the launcher)
+    int rider_rows, ncell, rider_per;   // rider_per: rows per rider block (launcher)
+    StackBulkArgs rider;
 };
 int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream);
+// true if that launch can carry rider blocks (narrow fp32 tiles, no XPART, the
+// stack rows fit the cell's LDS)
+bool pcm_cell_bwd_takes_rider(const CellBwdArgs &a, int D, int W);
 // how many partials (stride xpart_stride, to be summed in order) that launch
 // leaves dx in; 1 = the plain result
 int pcm_cell_bwd_xparts(const CellBwdArgs &a);
@@ -260,8 +284,14 @@ struct StackBwdArgs {
     const float *g_hprev;    // [B, Hp] top-layer hidden before step t-1
     const float *ctrl_w, *push_w;
     long long g_ld_dout;
+    // pcm_launch_stack_bwd_finish only: the bulk's control sums; dS_next /
+    // dS_prev are then read / corrected in rows 0 and 1 only
+    const float *psum;
 };
 int pcm_launch_stack_bwd(const StackBwdArgs &a, hipStream_t stream);
+// the critical-chain remainder of the stack adjoint when the bulk rode in the
+// top cell's launch (StackBulkArgs)
+int pcm_launch_stack_bwd_finish(const StackBwdArgs &a, hipStream_t stream);
 
 // x[b][j] *= dropout multiplier of (seed, layer, t, b, j)
 int pcm_launch_dropout_mask_mul(float *x, long long ldx, int B, int H,

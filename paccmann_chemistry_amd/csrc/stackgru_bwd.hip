@@ -10,6 +10,7 @@
 //              takes that layer's gate gradient of step t-1 right there (its
 //              last operand), saving a launch per step
 #include <stdlib.h>
+#include <algorithm>
 
 #include "stackgru.h"
 
@@ -303,6 +304,210 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
     if (a.gate_mode) gate_part();
 }
 
+// ---- the stack adjoint in two parts ---------------------------------------------
+// stack_bwd_kernel sits between the layer-0 reverse cell (whose stack-top
+// gradient it consumes) and the top cell of the step below (whose gate gradient
+// it produces), but only rows 0 and 1 of its 30 KB-per-row elementwise work
+// depend on that stack-top gradient: dL/dS'_t = G + [dtop in row 0], and both the
+// adjoint and the control sums are linear in it.  The bulk (this function; one
+// batch row per block, called from the extra blocks of the top layer's reverse
+// cell launch) runs on G alone, beside the cells; stack_bwd_finish_kernel adds
+// the dtop terms.  sm: 2 * DWp + 32 floats of LDS.
+__device__ __forceinline__ void stack_bwd_bulk(const StackBulkArgs &a, float *sm,
+                                               int b, int tid) {
+    const int W = a.W, D = a.D, DW = D * W;
+    const int DWp = (DW + 3) & ~3;
+    const float inv_W = 1.0f / (float)W;
+    float *Srow = sm, *Grow = sm + DWp, *red = Grow + DWp;   // red: [3][8]
+    const int lane = tid & 63, wave = tid >> 6;
+    const float *c = a.av + (long long)b * a.AVW;
+    const float a0 = c[0], a1 = c[1], a2 = c[2];
+    const bool frozen = a.lengths && a.t >= a.lengths[b];
+    const float *Sg = a.S_prev + (long long)b * DW;
+    const float *Gg = a.dS_next ? a.dS_next + (long long)b * DW : nullptr;
+    if ((DW & 3) == 0) {
+        for (int q = tid; q < (DW >> 2); q += BTHREADS) {
+            *(f32x4 *)(Srow + q * 4) = *(const f32x4 *)(Sg + q * 4);
+            *(f32x4 *)(Grow + q * 4) =
+                Gg ? *(const f32x4 *)(Gg + q * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    } else {
+        for (int e = tid; e < DW; e += BTHREADS) {
+            Srow[e] = Sg[e];
+            Grow[e] = Gg ? Gg[e] : 0.f;
+        }
+    }
+    __syncthreads();
+    float s_push = 0.f, s_pop = 0.f, s_noop = 0.f;
+    float *dSp = a.dS_prev + (long long)b * DW;
+    for (int e = tid; e < DW; e += BTHREADS) {
+        const float g = Grow[e];
+        if (frozen) { dSp[e] = g; continue; }
+        const int d = pcm_fdiv(e, inv_W), w = e - d * W;
+        const float sv = Srow[e];
+        const float up = d == 0 ? c[3 + w] : Srow[e - W];
+        const float dn = d == D - 1 ? 0.f : Srow[e + W];
+        s_push = fmaf(g, up, s_push);
+        s_pop = fmaf(g, dn, s_pop);
+        s_noop = fmaf(g, sv, s_noop);
+        // S[d] feeds S'[d] (no-op), S'[d+1] (push) and S'[d-1] (pop)
+        float v = a2 * g;
+        if (d + 1 < D) v += a0 * Grow[e + W];
+        if (d >= 1) v += a1 * Grow[e - W];
+        dSp[e] = v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s_push += __shfl_xor(s_push, off, 64);
+        s_pop += __shfl_xor(s_pop, off, 64);
+        s_noop += __shfl_xor(s_noop, off, 64);
+    }
+    if (lane == 0) {
+        red[0 * 8 + wave] = s_push;
+        red[1 * 8 + wave] = s_pop;
+        red[2 * 8 + wave] = s_noop;
+    }
+    __syncthreads();
+    if (tid < 3) {
+        float v = 0.f;
+        for (int w8 = 0; w8 < 8; ++w8) v += red[tid * 8 + w8];
+        a.psum[(long long)b * 4 + tid] = v;
+    }
+}
+
+// One block per batch row.  Takes the bulk's control sums and dL/dS_{t-1}, adds
+// the stack-top gradient's share (dL/dS'_t[0] += dtop: the no-op term of row 0,
+// the pop term of row 1, three W-long dot products), then softmax / tanh
+// backward, dc / du, and -- as stack_bwd_kernel -- the top layer's gate gradient
+// of step t - 1.
+__global__ __launch_bounds__(BTHREADS) void stack_bwd_finish_kernel(StackBwdArgs a) {
+    __shared__ float avs[64], dcu[64], red3[3];
+    const int W = a.W, D = a.D, DW = D * W;
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x;
+    struct GatePre { float d, r, z, n, g, hp, dout; };
+    auto gate_load = [&](int j) -> GatePre {
+        GatePre q = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const int b = b0;
+        if (b >= a.gate_B || j >= a.H) return q;
+        q.d = a.g_dh[(long long)b * a.Hp + j];
+        if (a.gate_mode == 1) {
+            const float *g = a.g_gates + (long long)b * 4 * a.H;
+            q.r = g[j]; q.z = g[a.H + j]; q.n = g[2 * a.H + j];
+            q.g = g[3 * a.H + j];
+            q.hp = a.g_hprev[(long long)b * a.Hp + j];
+            if (a.g_dout) q.dout = a.g_dout[(long long)b * a.g_ld_dout + j];
+        }
+        return q;
+    };
+    // (the column of [Wc ; Ws] is fetched at the point of use: requested up front,
+    // 64 loads per thread in front of everything else, the launch measured 9.2 us
+    // against 8.0)
+    GatePre gpre = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto gate_part = [&]() {
+        const int H = a.H, NO = 3 + W;
+        const int b = b0;
+        if (b >= a.gate_B) return;
+        for (int j = tid; j < H; j += BTHREADS) {
+            float s = 0.f;
+#pragma unroll
+            for (int o = 0; o < 3; ++o)
+                s = fmaf(dcu[o], a.ctrl_w[(long long)o * H + j], s);
+#pragma unroll 16
+            for (int o = 3; o < NO; ++o)
+                s = fmaf(dcu[o], a.push_w[(long long)(o - 3) * H + j], s);
+            const GatePre q = j == tid ? gpre : gate_load(j);
+            float *dh = a.g_dh + (long long)b * a.Hp + j;
+            const float d = q.d + s;
+            if (a.gate_mode == 2) { *dh = d; continue; }
+            float *g = a.g_gates + (long long)b * 4 * H;
+            if (a.lengths && a.t - 1 >= a.lengths[b]) {
+                g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f;
+                g[3 * H + j] = 0.f;
+                *dh = d;
+                continue;
+            }
+            gate_grad_vals(d + q.dout, q.r, q.z, q.n, q.g, q.hp, g, H, j, dh);
+        }
+    };
+    if (tid < 64) dcu[tid] = 0.f;
+    if (b0 >= a.B) {
+        // rows that finish at step t-1 (shrinking active batch): the gate
+        // gradient only
+        if (a.gate_mode) gpre = gate_load(tid);
+        __syncthreads();
+        gate_part();
+        return;
+    }
+    const int b = b0;
+    const bool frozen = a.lengths && a.t >= a.lengths[b];
+    if (tid < a.AVW && tid < 64) avs[tid] = a.av[(long long)b * a.AVW + tid];
+    // wave 0: lane w owns column w of the stack top (W <= 64, checked on the host)
+    float g0 = 0.f;
+    const bool col = tid < W;             // this lane holds a stack-top column
+    const bool live = col && !frozen;
+    constexpr int PMAX = 16;
+    float part[PMAX], s0 = 0.f, s1 = 0.f, vv = 0.f, c1 = 0.f, c2 = 0.f, o0 = 0.f,
+                      o1 = 0.f, ps = 0.f;
+    const float *src = a.dtop + (long long)b * a.Wp + tid;
+    float *d0 = a.dS_prev + (long long)b * DW + tid;
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p)
+        part[p] = (live && p < a.dtop_parts) ? src[p * a.dtop_stride] : 0.f;
+    if (live) {
+        s0 = a.S_prev[(long long)b * DW + tid];
+        s1 = D > 1 ? a.S_prev[(long long)b * DW + W + tid] : 0.f;
+        vv = a.av[(long long)b * a.AVW + 3 + tid];
+        c1 = a.av[(long long)b * a.AVW + 1];
+        c2 = a.av[(long long)b * a.AVW + 2];
+        o0 = *d0;
+        o1 = D > 1 ? d0[W] : 0.f;
+    }
+    if (col) g0 = a.dS_next ? a.dS_next[(long long)b * DW + tid] : 0.f;
+    if (tid < 3) ps = a.psum[(long long)b * 4 + tid];
+    asm volatile("" ::: "memory");
+    if (a.gate_mode) gpre = gate_load(tid);   // (cold lines: requested last)
+    if (tid < 64) {
+        float p_push = 0.f, p_pop = 0.f, p_noop = 0.f;
+        if (live) {
+            float dt = part[0];
+#pragma unroll
+            for (int p = 1; p < PMAX; ++p) dt += part[p];
+            for (int p = PMAX; p < a.dtop_parts; ++p) dt += src[p * a.dtop_stride];
+            p_push = dt * vv; p_pop = dt * s1; p_noop = dt * s0;
+            *d0 = fmaf(c2, dt, o0);                 // no-op: S[0] feeds S'[0]
+            if (D > 1) d0[W] = fmaf(c1, dt, o1);    // pop:   S[1] feeds S'[0]
+            g0 += dt;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            p_push += __shfl_xor(p_push, off, 64);
+            p_pop += __shfl_xor(p_pop, off, 64);
+            p_noop += __shfl_xor(p_noop, off, 64);
+        }
+        // lanes 0..2 hold the bulk's push / pop / no-op sums
+        if (tid < 3) red3[tid] = ps + (tid == 0 ? p_push : (tid == 1 ? p_pop : p_noop));
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float sp = red3[0], so = red3[1], sn = red3[2];
+        // softmax backward: dc_i = a_i * (da_i - sum_j a_j da_j)
+        const float dot = avs[0] * sp + avs[1] * so + avs[2] * sn;
+        dcu[0] = frozen ? 0.f : avs[0] * (sp - dot);
+        dcu[1] = frozen ? 0.f : avs[1] * (so - dot);
+        dcu[2] = frozen ? 0.f : avs[2] * (sn - dot);
+    }
+    // dv[w] = a_push * G[0][w]; du = dv * (1 - v^2)
+    if (tid < W && !frozen) {
+        const float v = avs[3 + tid];
+        dcu[3 + tid] = avs[0] * g0 * (1.f - v * v);
+    }
+    __syncthreads();
+    // keep dc / du for the time-parallel dWc / dWs products
+    if (tid < a.AVW) a.av[(long long)b * a.AVW + tid] = tid < 64 ? dcu[tid] : 0.f;
+    if (a.gate_mode) gate_part();
+}
+
 
 // ------------------------------------------------------------------------------
 // fused reverse GRU cell: dgates . W on fp32 MFMA, LDS-staged 64-wide K chunks,
@@ -391,7 +596,11 @@ __device__ __forceinline__ void raw_barrier() {
 // ct) adds, after its own K loop, the product of K part ct / ncx and input-side
 // column tile ct % ncx (ncx = Kxp / 32) in a second accumulator and stores it
 // as partial number ct / ncx; the stack adjoint sums the partials in order.
-template <int BCN, int BNSTAGE, bool XPART = false, bool BF16 = false>
+// RIDER: blocks past the cell's own tiles run the bulk stack adjoint of the step
+// (stack_bwd_bulk, one batch row each) in the launch's shadow: two cell blocks and
+// one rider block fit a CU (48 VGPRs, 3 x 48 KiB of LDS).
+template <int BCN, int BNSTAGE, bool XPART = false, bool BF16 = false,
+          bool RIDER = false>
 __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
     static_assert(!XPART || BCN == 32, "XPART rides on the narrow tile");
     constexpr int BSTAGE = (BCM + BCN) * BCK;    // floats per LDS stage
@@ -402,6 +611,17 @@ __global__ __launch_bounds__(512) void gru_cell_bwd_kernel(CellBwdArgs a) {
     static_assert(BCELL_LDS >= 4 * NTL * 1024, "reduction buffer must fit");
     __shared__ __attribute__((aligned(16))) float lds[BCELL_LDS];
     const int tid = threadIdx.x;
+    if constexpr (RIDER) {
+        if ((int)blockIdx.x >= a.ncell) {
+            // rider_per rows per block, one after the other
+            const int r0 = ((int)blockIdx.x - a.ncell) * a.rider_per;
+            for (int r = r0; r < min(r0 + a.rider_per, a.rider.B); ++r) {
+                if (r > r0) __syncthreads();
+                stack_bwd_bulk(a.rider, lds, r, tid);
+            }
+            return;
+        }
+    }
     const int lane = tid & 63;
     // wave index as a scalar: role branches and LDS-DMA bases stay on the SALU
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -760,6 +980,13 @@ int pcm_cell_bwd_xparts(const CellBwdArgs &a) {
     return (3 * a.H / BCK) % parts == 0 ? parts : 1;
 }
 
+bool pcm_cell_bwd_takes_rider(const CellBwdArgs &a, int D, int W) {
+    const int DWp = (D * W + 3) & ~3;
+    // (the narrow tile's three stages: 3 * (32 + 32) * 64 floats)
+    return !g_pcm_matmul_bf16 && bwd_narrow(a) &&
+           2 * DWp + 32 <= 3 * (BCM + 32) * BCK;
+}
+
 int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream) {
     const int nbt = (a.B + BCM - 1) / BCM;
     const bool narrow = bwd_narrow(a);
@@ -770,6 +997,24 @@ int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream) {
     b.reg_cols = (nct + 3) / 4;
     b.reg_rows = (nbt + 1) / 2;
     dim3 grid(8 * b.reg_cols * b.reg_rows);
+    if (a.rider_rows > 0) {
+        PCM_REQUIRE(pcm_cell_bwd_takes_rider(a, a.rider.D, a.rider.W), PCM_EINVAL,
+                    "cell_bwd: this launch cannot carry rider blocks");
+        static const int per = [] {
+            const char *e = getenv("PCM_STACK_RIDER_PER");
+            return e ? std::max(1, atoi(e)) : 1;
+        }();
+        b.ncell = (int)grid.x;
+        b.rider_per = per;
+        const dim3 rgrid(grid.x + (a.rider_rows + per - 1) / per);
+        if (xpart)
+            PCM_LAUNCH((gru_cell_bwd_kernel<32, 3, true, false, true>), rgrid,
+                       dim3(512), 0, stream, b);
+        else
+            PCM_LAUNCH((gru_cell_bwd_kernel<32, 3, false, false, true>), rgrid,
+                       dim3(512), 0, stream, b);
+        return 0;
+    }
     if (g_pcm_matmul_bf16) {
         if (xpart)
             PCM_LAUNCH((gru_cell_bwd_kernel<32, 3, true, true>), grid, dim3(512),
@@ -836,6 +1081,14 @@ int pcm_launch_stack_bwd(const StackBwdArgs &a, hipStream_t stream) {
     else
         PCM_LAUNCH(stack_bwd_kernel<2>, dim3((rows + 1) / 2),
                            dim3(BTHREADS), 2 * row_bytes, stream, a);
+    return 0;
+}
+
+int pcm_launch_stack_bwd_finish(const StackBwdArgs &a, hipStream_t stream) {
+    PCM_REQUIRE(a.psum && a.W <= 61 && a.AVW <= 64, PCM_EINVAL,
+                "stack_bwd_finish: needs the bulk's sums and W <= 61");
+    const int rows = a.gate_mode ? (a.gate_B > a.B ? a.gate_B : a.B) : a.B;
+    PCM_LAUNCH(stack_bwd_finish_kernel, dim3(rows), dim3(BTHREADS), 0, stream, a);
     return 0;
 }
 

@@ -434,6 +434,7 @@ def test_large_stack_gradients_and_limit():
     {'PCM_CHAINS': '2', 'PCM_DW_CUTS': '45,75,90'},
     {'PCM_FUSE_STACK': '1'},
     {'PCM_ROW_SKIP': '0'},
+    {'PCM_STACK_SPLIT': '0'},
 ])
 def test_opt_in_recurrence_variants(env):
     """The forms of the recurrence that are built but not the default (measured
@@ -442,7 +443,10 @@ def test_opt_in_recurrence_variants(env):
     (PCM_PERSIST=1), the batch walked as two half-batch chains on two
     streams (PCM_CHAINS=2) and the stack step fused into the forward cells
     (PCM_FUSE_STACK=1: two launches per forward step); PCM_ROW_SKIP=0 is the
-    packed-mode weight-gradient reduction over all rows, zeros included.  The switches are read once per process, hence a
+    packed-mode weight-gradient reduction over all rows, zeros included;
+    PCM_STACK_SPLIT=0 the stack adjoint as one launch on the chain (the
+    default since round 3 splits it: bulk as rider blocks of the layer-0
+    reverse cell, stack-top terms + gate gradient on the chain).  The switches are read once per process, hence a
     child process: the full-size training step (every gradient against the
     oracle, with and without dropout), the B=4096 rows and the packed / padded
     data-parallel shard test."""
