@@ -64,6 +64,9 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(GateBwdArgs a) {
 // rows are staged in LDS (one HBM read each), the three control-gradient sums
 // are block-reduced, and the block finishes with dL/dh_top += dc.Wc + du.Ws.
 constexpr int BTHREADS = 512;
+#ifndef FIN_UNROLL
+#define FIN_UNROLL 16
+#endif
 
 template <int BROWS>
 __global__ __launch_bounds__(BTHREADS) void stack_bwd_kernel(StackBwdArgs a) {
@@ -375,20 +378,24 @@ __device__ __forceinline__ void stack_bwd_bulk(const StackBulkArgs &a, float *sm
     }
 }
 
-// One block per batch row.  Takes the bulk's control sums and dL/dS_{t-1}, adds
-// the stack-top gradient's share (dL/dS'_t[0] += dtop: the no-op term of row 0,
-// the pop term of row 1, three W-long dot products), then softmax / tanh
-// backward, dc / du, and -- as stack_bwd_kernel -- the top layer's gate gradient
-// of step t - 1.
+// R batch rows per block.  Takes the bulk's control sums and dL/dS_{t-1}, adds the
+// stack-top gradient's share (dL/dS'_t[0] += dtop: the no-op term of row 0, the
+// pop term of row 1, three W-long dot products; wave r serves row r), then
+// softmax / tanh backward, dc / du, and -- as stack_bwd_kernel -- the top layer's
+// gate gradient of step t - 1: dL/dh += dc.Wc + du.Ws.  That product reads the
+// whole 108 KB [Wc ; Ws] per block whatever the number of rows (55 MB per launch
+// through the L2s at one row per block); R rows share every weight a thread
+// loads -- and measured 2-3 x slower (launcher), so R = 1 is what runs.
+template <int R>
 __global__ __launch_bounds__(BTHREADS) void stack_bwd_finish_kernel(StackBwdArgs a) {
-    __shared__ float avs[64], dcu[64], red3[3];
+    static_assert(R <= BTHREADS / 64, "one wave per row");
+    __shared__ float dcu[R][64];
     const int W = a.W, D = a.D, DW = D * W;
-    const int tid = threadIdx.x;
-    const int b0 = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b0 = blockIdx.x * R;
     struct GatePre { float d, r, z, n, g, hp, dout; };
-    auto gate_load = [&](int j) -> GatePre {
+    auto gate_load = [&](int b, int j) -> GatePre {
         GatePre q = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const int b = b0;
         if (b >= a.gate_B || j >= a.H) return q;
         q.d = a.g_dh[(long long)b * a.Hp + j];
         if (a.gate_mode == 1) {
@@ -400,75 +407,49 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_finish_kernel(StackBwdArgs
         }
         return q;
     };
+    for (int idx = tid; idx < R * 64; idx += BTHREADS) dcu[idx >> 6][idx & 63] = 0.f;
+
+    // ---- wave r: the stack-top terms of row b0 + r ---------------------------------
     // (the column of [Wc ; Ws] is fetched at the point of use: requested up front,
     // 64 loads per thread in front of everything else, the launch measured 9.2 us
     // against 8.0)
-    GatePre gpre = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto gate_part = [&]() {
-        const int H = a.H, NO = 3 + W;
-        const int b = b0;
-        if (b >= a.gate_B) return;
-        for (int j = tid; j < H; j += BTHREADS) {
-            float s = 0.f;
-#pragma unroll
-            for (int o = 0; o < 3; ++o)
-                s = fmaf(dcu[o], a.ctrl_w[(long long)o * H + j], s);
-#pragma unroll 16
-            for (int o = 3; o < NO; ++o)
-                s = fmaf(dcu[o], a.push_w[(long long)(o - 3) * H + j], s);
-            const GatePre q = j == tid ? gpre : gate_load(j);
-            float *dh = a.g_dh + (long long)b * a.Hp + j;
-            const float d = q.d + s;
-            if (a.gate_mode == 2) { *dh = d; continue; }
-            float *g = a.g_gates + (long long)b * 4 * H;
-            if (a.lengths && a.t - 1 >= a.lengths[b]) {
-                g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f;
-                g[3 * H + j] = 0.f;
-                *dh = d;
-                continue;
-            }
-            gate_grad_vals(d + q.dout, q.r, q.z, q.n, q.g, q.hp, g, H, j, dh);
-        }
-    };
-    if (tid < 64) dcu[tid] = 0.f;
-    if (b0 >= a.B) {
-        // rows that finish at step t-1 (shrinking active batch): the gate
-        // gradient only
-        if (a.gate_mode) gpre = gate_load(tid);
-        __syncthreads();
-        gate_part();
-        return;
-    }
-    const int b = b0;
-    const bool frozen = a.lengths && a.t >= a.lengths[b];
-    if (tid < a.AVW && tid < 64) avs[tid] = a.av[(long long)b * a.AVW + tid];
-    // wave 0: lane w owns column w of the stack top (W <= 64, checked on the host)
-    float g0 = 0.f;
-    const bool col = tid < W;             // this lane holds a stack-top column
+    const int b = b0 + wave;
+    const bool row = wave < R && b < a.B;
+    const bool frozen = row && a.lengths && a.t >= a.lengths[b];
+    const bool col = row && lane < W;     // this lane holds a stack-top column
     const bool live = col && !frozen;
     constexpr int PMAX = 16;
-    float part[PMAX], s0 = 0.f, s1 = 0.f, vv = 0.f, c1 = 0.f, c2 = 0.f, o0 = 0.f,
-                      o1 = 0.f, ps = 0.f;
-    const float *src = a.dtop + (long long)b * a.Wp + tid;
-    float *d0 = a.dS_prev + (long long)b * DW + tid;
+    float part[PMAX], s0 = 0.f, s1 = 0.f, c1 = 0.f, c2 = 0.f, o0 = 0.f, o1 = 0.f,
+                      ps = 0.f, g0 = 0.f, av_l = 0.f;
+    const float *src = a.dtop + (long long)b * a.Wp + lane;
+    float *d0 = a.dS_prev + (long long)b * DW + lane;
 #pragma unroll
     for (int p = 0; p < PMAX; ++p)
         part[p] = (live && p < a.dtop_parts) ? src[p * a.dtop_stride] : 0.f;
+    if (row && lane < a.AVW) av_l = a.av[(long long)b * a.AVW + lane];
     if (live) {
-        s0 = a.S_prev[(long long)b * DW + tid];
-        s1 = D > 1 ? a.S_prev[(long long)b * DW + W + tid] : 0.f;
-        vv = a.av[(long long)b * a.AVW + 3 + tid];
+        s0 = a.S_prev[(long long)b * DW + lane];
+        s1 = D > 1 ? a.S_prev[(long long)b * DW + W + lane] : 0.f;
         c1 = a.av[(long long)b * a.AVW + 1];
         c2 = a.av[(long long)b * a.AVW + 2];
         o0 = *d0;
         o1 = D > 1 ? d0[W] : 0.f;
     }
-    if (col) g0 = a.dS_next ? a.dS_next[(long long)b * DW + tid] : 0.f;
-    if (tid < 3) ps = a.psum[(long long)b * 4 + tid];
+    if (col) g0 = a.dS_next ? a.dS_next[(long long)b * DW + lane] : 0.f;
+    if (row && lane < 3) ps = a.psum[(long long)b * 4 + lane];
     asm volatile("" ::: "memory");
-    if (a.gate_mode) gpre = gate_load(tid);   // (cold lines: requested last)
-    if (tid < 64) {
+    // the gate operands of this thread's column, all R rows (cold lines:
+    // requested last, used last)
+    GatePre gpre[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        gpre[r] = GatePre{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (a.gate_mode) gpre[r] = gate_load(b0 + r, tid);
+    }
+    if (wave < R) {
         float p_push = 0.f, p_pop = 0.f, p_noop = 0.f;
+        // v of this lane's column: av[3 + lane] sits in lane 3 + lane
+        const float vv = __shfl(av_l, min(lane + 3, 63), 64);
         if (live) {
             float dt = part[0];
 #pragma unroll
@@ -485,27 +466,65 @@ __global__ __launch_bounds__(BTHREADS) void stack_bwd_finish_kernel(StackBwdArgs
             p_pop += __shfl_xor(p_pop, off, 64);
             p_noop += __shfl_xor(p_noop, off, 64);
         }
-        // lanes 0..2 hold the bulk's push / pop / no-op sums
-        if (tid < 3) red3[tid] = ps + (tid == 0 ? p_push : (tid == 1 ? p_pop : p_noop));
+        // lanes 0..2 hold the bulk's push / pop / no-op sums; softmax backward:
+        // dc_i = a_i * (da_i - sum_j a_j da_j)
+        const float da = ps + (lane == 0 ? p_push : (lane == 1 ? p_pop : p_noop));
+        const float ada = lane < 3 ? av_l * da : 0.f;
+        const float dot = __shfl(ada, 0, 64) + __shfl(ada, 1, 64) + __shfl(ada, 2, 64);
+        const float a_push = __shfl(av_l, 0, 64);
+        float out = 0.f;
+        if (row && !frozen) {
+            if (lane < 3) out = av_l * (da - dot);
+            // dv[w] = a_push * G[0][w]; du = dv * (1 - v^2): column w -> slot 3 + w
+        }
+        // move column results to their slots: slot o = 3 + w comes from lane o - 3
+        const float du = (live) ? a_push * g0 * (1.f - vv * vv) : 0.f;
+        const float du_s = __shfl(du, max(lane - 3, 0), 64);
+        if (row && !frozen && lane >= 3 && lane < 3 + W) out = du_s;
+        dcu[wave][lane] = out;
+        // keep dc / du for the time-parallel dWc / dWs products
+        if (row && lane < a.AVW) a.av[(long long)b * a.AVW + lane] = out;
     }
     __syncthreads();
-    if (tid == 0) {
-        const float sp = red3[0], so = red3[1], sn = red3[2];
-        // softmax backward: dc_i = a_i * (da_i - sum_j a_j da_j)
-        const float dot = avs[0] * sp + avs[1] * so + avs[2] * sn;
-        dcu[0] = frozen ? 0.f : avs[0] * (sp - dot);
-        dcu[1] = frozen ? 0.f : avs[1] * (so - dot);
-        dcu[2] = frozen ? 0.f : avs[2] * (sn - dot);
+    if (!a.gate_mode) return;
+
+    // ---- all threads: dL/dh_{t-1} += dc.Wc + du.Ws, gate derivatives in place --------
+    const int H = a.H, NO = 3 + W;
+    for (int j = tid; j < H; j += BTHREADS) {
+        float s[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            const float w = a.ctrl_w[(long long)o * H + j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) s[r] = fmaf(dcu[r][o], w, s[r]);
+        }
+#pragma unroll FIN_UNROLL
+        for (int o = 3; o < NO; ++o) {
+            const float w = a.push_w[(long long)(o - 3) * H + j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) s[r] = fmaf(dcu[r][o], w, s[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int bb = b0 + r;
+            if (bb >= a.gate_B) continue;
+            const GatePre q = j == tid ? gpre[r] : gate_load(bb, j);
+            float *dh = a.g_dh + (long long)bb * a.Hp + j;
+            const float d = q.d + s[r];
+            if (a.gate_mode == 2) { *dh = d; continue; }
+            float *g = a.g_gates + (long long)bb * 4 * H;
+            if (a.lengths && a.t - 1 >= a.lengths[bb]) {
+                // frozen row: h_t = h_{t-1}; its output carries no gradient
+                g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f;
+                g[3 * H + j] = 0.f;
+                *dh = d;
+                continue;
+            }
+            gate_grad_vals(d + q.dout, q.r, q.z, q.n, q.g, q.hp, g, H, j, dh);
+        }
     }
-    // dv[w] = a_push * G[0][w]; du = dv * (1 - v^2)
-    if (tid < W && !frozen) {
-        const float v = avs[3 + tid];
-        dcu[3 + tid] = avs[0] * g0 * (1.f - v * v);
-    }
-    __syncthreads();
-    // keep dc / du for the time-parallel dWc / dWs products
-    if (tid < a.AVW) a.av[(long long)b * a.AVW + tid] = tid < 64 ? dcu[tid] : 0.f;
-    if (a.gate_mode) gate_part();
 }
 
 
@@ -1088,7 +1107,24 @@ int pcm_launch_stack_bwd_finish(const StackBwdArgs &a, hipStream_t stream) {
     PCM_REQUIRE(a.psum && a.W <= 61 && a.AVW <= 64, PCM_EINVAL,
                 "stack_bwd_finish: needs the bulk's sums and W <= 61");
     const int rows = a.gate_mode ? (a.gate_B > a.B ? a.gate_B : a.B) : a.B;
-    PCM_LAUNCH(stack_bwd_finish_kernel, dim3(rows), dim3(BTHREADS), 0, stream, a);
+    static const int per = [] {
+        // measured at batch 512 (us per launch): 1 row 7.0, 2 rows 16.4, 4 rows
+        // 17.1, 8 rows 21.0 -- as with the fused kernel, one row per block
+        const char *e = getenv("PCM_STACK_FINISH_ROWS");
+        return e ? atoi(e) : 1;
+    }();
+    if (per >= 8)
+        PCM_LAUNCH(stack_bwd_finish_kernel<8>, dim3((rows + 7) / 8), dim3(BTHREADS),
+                   0, stream, a);
+    else if (per >= 4)
+        PCM_LAUNCH(stack_bwd_finish_kernel<4>, dim3((rows + 3) / 4), dim3(BTHREADS),
+                   0, stream, a);
+    else if (per >= 2)
+        PCM_LAUNCH(stack_bwd_finish_kernel<2>, dim3((rows + 1) / 2), dim3(BTHREADS),
+                   0, stream, a);
+    else
+        PCM_LAUNCH(stack_bwd_finish_kernel<1>, dim3(rows), dim3(BTHREADS), 0, stream,
+                   a);
     return 0;
 }
 
