@@ -206,7 +206,7 @@ def pmc_traffic(kernel):
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         with open(path) as f:
-            return json.load(f)['kernels'][kernel.split(' ')[0]][
+            return json.load(f)['kernels'][kernel.split(' ')[0].split('<')[0]][
                 'bytes_per_launch']
     except (OSError, KeyError, ValueError):
         return None
