@@ -626,9 +626,27 @@ def main():
         tokens_per_step = world * tokens_per_batch
         value = tokens_per_step * args.steps / elapsed
         entries = []
+        # Round 3: at this shape the forward stack step has no launch of its own
+        # (api.hip: enqueue_step, `fuse`): layer 0's cell derives controls, push
+        # value and the new stack top in a prologue and the top cell's launch
+        # carries the stack update as extra blocks.  The probe shows it (the
+        # stack family then has the first step's launches only); the cells'
+        # entries say so, their priced work stays the GEMM FLOPs.
+        fused_fwd = any(n.startswith('stack_step_fwd') and 0 < k < SEQ_LEN
+                        for n, _, _, _, k in probed)
         for name, bound, work, total_ms, launches in probed:
             if launches <= 0:
                 continue
+            if fused_fwd and name == 'gru_cell_fwd_kernel (layer 0)':
+                name = ('gru_cell_fwd_kernel (layer 0, + the stack step\'s '
+                        'controls / push value / new stack top as a prologue, '
+                        'not priced)')
+            elif fused_fwd and name == 'gru_cell_fwd_kernel (layers >= 1)':
+                name = ('gru_cell_fwd_kernel (layers >= 1, + the stack update '
+                        'as rider blocks: 2*D*W*4 bytes per row, not priced)')
+            elif fused_fwd and name.startswith('stack_step_fwd'):
+                name = ('stack_step_fwd_kernel (first step of a sequence only: '
+                        'fused into the cells elsewhere)')
             total_ms = max(total_ms - launches * probe_offset_us * 1e-3, 1e-9)
             avg_s = total_ms / launches * 1e-3
             if name.startswith('gemm_tn'):
@@ -662,13 +680,24 @@ def main():
                 ach = flop / (ms * 1e-3) / 1e12
                 symbols.append({
                     'bound': 'mfma',
-                    'kernel': 'gru_cell_fwd_kernel (all layers)',
+                    'kernel': 'gru_cell_fwd_kernel (all layers'
+                              + (', stack step fused in: 2 launches per '
+                                 'forward step' if fused_fwd else '') + ')',
                     'achieved': ach, 'peak': mfma_peak, 'unit': 'TFLOP/s',
                     'frac': ach / mfma_peak, 'traffic': fwd[0]['traffic'],
                     'avg_launch_us': ms * 1e3 / n, 'launches': n,
                     'ms_per_step': ms,
                 })
             roofline = dict(max(symbols, key=lambda e: e['ms_per_step']))
+            if fused_fwd and roofline['kernel'].startswith('gru_cell_fwd'):
+                roofline['note'] = (
+                    'priced on the cells\' GEMM FLOPs alone although the two '
+                    'launches now also carry the whole forward stack step '
+                    '(control softmax, push tanh, new stack top, 2*D*W*4 bytes '
+                    'per row of stack update); as three launches per step '
+                    '(PCM_FUSE_STACK=0) the same cells read 13.97 / 18.43 us = '
+                    '0.49 of peak and the step 0.4 ms more '
+                    '(profiles/r03_bench_unfused_forward.json)')
             roofline['sample'] = (
                 'kernel begin -> end from the events hipExtLaunchKernelGGL '
                 'binds to each dispatch, every launch of one untimed step '

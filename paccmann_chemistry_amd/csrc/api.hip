@@ -267,6 +267,17 @@ int pcm_sg_layout(const pcm_dims *d, int steps, int training, int dropout,
 
 static const size_t GEMM_SCRATCH_FLOATS = 40u * 1024u * 1024u;
 
+// compute units of the current device (256 on MI355X), looked up once
+static int pcm_cu_count() {
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess)
+            (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
+    }();
+    return cus;
+}
+
 
 int pcm_sg_scratch(const SGLayout &lay, SGScratch *o) {
     memset(o, 0, sizeof(*o));
@@ -336,18 +347,25 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
     // block of a row tile pulls the same 16 partials per row: 2.5 us) and the
     // update blocks (+1.9 us on the top cell) cost what the stack launch costs,
     // so the default keeps the three-launch step and its per-kernel pricing.
-    static const bool fuse_enabled = [] {
+    // Round 3: measured again with this round's reverse pass, batch 512: 25.37
+    // against 25.75 ms per step (three A/B pairs), level at the other batch sizes
+    // where it engages and slower at batch 1024 (46.1 against 44.8) -- so it is
+    // the default where the cells' grid is at most one block per CU (the
+    // benchmarked shape), PCM_FUSE_STACK=0 / 1 force it off / on.
+    static const int fuse_mode = [] {
         const char *e = getenv("PCM_FUSE_STACK");
-        return e && atoi(e) == 1;
+        return e ? (atoi(e) == 1 ? 1 : 0) : -1;
     }();
     bool fuse = false;
-    if (fuse_enabled && lay.use_stack && lay.L >= 2 && cs_part && have_part &&
+    if (fuse_mode != 0 && lay.use_stack && lay.L >= 2 && cs_part && have_part &&
         *have_part == lay.Hn / 32 && lay.Kxp[0] == 64 && lay.Wp == 64 && lay.AVW <= 64 &&
         3 + lay.W <= 64 && lay.H == lay.Hn) {
         CellFwdArgs probe;
         memset(&probe, 0, sizeof(probe));
         probe.B = Bt; probe.Hn = lay.Hn;
         fuse = pcm_cell_fwd_tile(probe) == 32;
+        if (fuse_mode < 0 && (long long)((Bt + 31) / 32) * (lay.Hn / 32) > pcm_cu_count())
+            fuse = false;
     }
     if (lay.use_stack && !fuse) {
         StackFwdArgs s;

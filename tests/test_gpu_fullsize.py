@@ -432,7 +432,7 @@ def test_large_stack_gradients_and_limit():
     {'PCM_PERSIST': '2'},
     {'PCM_CHAINS': '2'},
     {'PCM_CHAINS': '2', 'PCM_DW_CUTS': '45,75,90'},
-    {'PCM_FUSE_STACK': '1'},
+    {'PCM_FUSE_STACK': '0'},
     {'PCM_ROW_SKIP': '0'},
     {'PCM_STACK_SPLIT': '0'},
 ])
@@ -441,8 +441,9 @@ def test_opt_in_recurrence_variants(env):
     slower than, or level with, the launch chain at batch 512): the
     persistent weight-stationary forward kernel with in-launch group hand-offs
     (PCM_PERSIST=1), the batch walked as two half-batch chains on two
-    streams (PCM_CHAINS=2) and the stack step fused into the forward cells
-    (PCM_FUSE_STACK=1: two launches per forward step); PCM_ROW_SKIP=0 is the
+    streams (PCM_CHAINS=2) and the forward stack step as a launch of its own
+    (PCM_FUSE_STACK=0: three launches per forward step; since round 3 the
+    default at batch 512 fuses it into the cells); PCM_ROW_SKIP=0 is the
     packed-mode weight-gradient reduction over all rows, zeros included;
     PCM_STACK_SPLIT=0 the stack adjoint as one launch on the chain (the
     default since round 3 splits it: bulk as rider blocks of the layer-0
