@@ -108,15 +108,76 @@ def test_full_size_training_step_matches_oracle(dropout):
     assert not bad, bad
 
 
-def test_packed_training_step_matches_oracle():
+@pytest.mark.parametrize('layers,depth,width,hidden,batch', [
+    (3, 3, 5, 64, 48),      # a middle layer between the rider's two hosts
+    (2, 1, 4, 64, 40),      # stack of depth 1: no row 1 for the pop term
+    (2, 6, 61, 128, 33),    # the widest stack the split adjoint takes, odd batch
+    (2, 4, 62, 64, 32),     # one wider: the fused adjoint launch
+    (2, 5, 7, 512, 512),    # hidden 512 / batch 512: forward stack step fused
+                            # into the cells, small stack
+], ids=['l3', 'depth1', 'w61', 'w62', 'b512_small_stack'])
+def test_fast_path_edge_shapes_match_oracle(layers, depth, width, hidden, batch):
+    """The kernels of the hidden % 64 == 0 path at the edges of what round 3's
+    two restructurings accept (the stack adjoint as rider blocks + finish launch:
+    two or more layers, stack width <= 61; the forward stack step fused into
+    the cells: one block per CU): a short training step, every gradient
+    against the oracle's autograd."""
+    from paccmann_chemistry_amd import vae_loss_function
+    steps = 9
+    p = dict(CONFIG, n_layers=layers, stack_depth=depth, stack_width=width,
+             rnn_cell_size=hidden, batch_size=batch, latent_dim=16,
+             vocab_size=20, embedding_size=20)
+    sd = W.make_state_dict(p, 4300 + layers + depth)
+    tokens = W.synthetic_tokens(steps, batch, p['vocab_size'], 4301)
+    targets = W.shifted_targets(tokens)
+    eps = torch.from_numpy(np.random.default_rng(4302).standard_normal(
+        (batch, p['latent_dim'])).astype(np.float32))
+    vae = _build_vae(p, sd)
+    dev = _dev()
+    dec_loss, mu, logvar = vae(tokens.to(dev), tokens.to(dev), targets.to(dev),
+                               eps=eps.to(dev))
+    total, _ = vae_loss_function(dec_loss, mu, logvar, kl_growth=0.003,
+                                 step=5000)
+    total.backward()
+    vae.check_tokens()
+    ref = {k: v.clone().requires_grad_('embedding' not in k)
+           for k, v in sd.items()}
+    r_mu, r_logvar = O.encoder_forward(
+        O.sub_params(ref, 'encoder'), tokens, p['stack_depth'])
+    z = O.reparameterize(r_mu, r_logvar, eps)
+    r_loss, r_logits, _ = O.decoder_forward(
+        O.sub_params(ref, 'decoder'), z, tokens, targets, p['stack_depth'])
+    r_total, _ = O.vae_loss(r_loss, r_mu, r_logvar, 0.003, step=5000)
+    r_total.backward()
+    assert _rel_to_max(mu, r_mu) < 1e-5
+    assert _rel_to_max(vae.decoder.logits, r_logits) < LOGIT_TOL
+    assert abs(total.item() - r_total.item()) < 1e-5 * abs(r_total.item())
+    bad = {}
+    for name, param in vae.named_parameters():
+        if ref[name].grad is None:
+            continue
+        err = _rel_to_max(param.grad, ref[name].grad)
+        if not err < GRAD_TOL:
+            bad[name] = err
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('shrink', [True, False],
+                         ids=['active_prefix', 'frozen_rows'])
+def test_packed_training_step_matches_oracle(shrink, monkeypatch):
     """Packed mode at a batch the K-major weight-gradient kernel takes (B=256,
     T=48, lengths 2..48, batch_sizes shrinking to 3 rows): the launches walk
     the still-running prefix of the batch and the weight-gradient products
     skip the 16-row chunks no sequence reaches (PCM_ROW_SKIP=0 multiplies the
     zeros instead; test_opt_in_recurrence_variants runs this test that way).
     Loss, mu, logits of the real steps and every gradient against the oracle's
-    packed semantics (vae.py:138-236, 352-389)."""
-    from paccmann_chemistry_amd import vae_loss_function
+    packed semantics (vae.py:138-236, 352-389).  frozen_rows: the same batch
+    through the all-rows path (finished rows frozen in place, what unsorted
+    lengths get), i.e. the length checks of the hidden-512 kernels -- the
+    reverse cells, the stack adjoint's rider blocks and its finish launch."""
+    from paccmann_chemistry_amd import ops, vae_loss_function
+    if not shrink:
+        monkeypatch.setattr(ops, 'SHRINK_ACTIVE_BATCH', False)
     batch, steps = 256, 48
     p = dict(CONFIG, batch_size=batch, batch_mode='packed')
     sd = W.make_state_dict(p, 4150)
