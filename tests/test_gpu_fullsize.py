@@ -109,13 +109,14 @@ def test_full_size_training_step_matches_oracle(dropout):
 
 
 @pytest.mark.parametrize('layers,depth,width,hidden,batch', [
+    (1, 3, 5, 64, 40),      # one layer: no rider host, the fused adjoint launch
     (3, 3, 5, 64, 48),      # a middle layer between the rider's two hosts
     (2, 1, 4, 64, 40),      # stack of depth 1: no row 1 for the pop term
     (2, 6, 61, 128, 33),    # the widest stack the split adjoint takes, odd batch
     (2, 4, 62, 64, 32),     # one wider: the fused adjoint launch
     (2, 5, 7, 512, 512),    # hidden 512 / batch 512: forward stack step fused
                             # into the cells, small stack
-], ids=['l3', 'depth1', 'w61', 'w62', 'b512_small_stack'])
+], ids=['l1', 'l3', 'depth1', 'w61', 'w62', 'b512_small_stack'])
 def test_fast_path_edge_shapes_match_oracle(layers, depth, width, hidden, batch):
     """The kernels of the hidden % 64 == 0 path at the edges of what round 3's
     two restructurings accept (the stack adjoint as rider blocks + finish launch:
