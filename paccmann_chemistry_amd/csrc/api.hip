@@ -367,8 +367,32 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         if (fuse_mode < 0 && (long long)((Bt + 31) / 32) * (lay.Hn / 32) > pcm_cu_count())
             fuse = false;
     }
+    // Opt-in (PCM_STACK_SPLIT64=rows per rider block), large batches (the 64 x 64
+    // forward tile + the MFMA stack step, 4096 rows and more): the stack launch
+    // computes controls, push value and the new stack TOP only, the 2 * D * W * 4
+    // bytes per row of the update ride as extra blocks in the top layer's
+    // launch.  Measured SLOWER at batch 4096 (encoder-only 169.9 k against
+    // 173.6 k molecules/s, ragged 213 k against 265 k): two 64 KiB cell blocks
+    // fill a CU's LDS, so the riders only start when cell blocks end -- at the
+    // launch's tail, on the chain again -- and the stack launch stays.
+    static const int split64_rows = [] {
+        const char *e = getenv("PCM_STACK_SPLIT64");   // rows per rider block
+        return e ? atoi(e) : 0;
+    }();
+    bool split64 = false;
+    if (lay.use_stack && !fuse && split64_rows > 0 && lay.L >= 2) {
+        StackFwdArgs ps;
+        memset(&ps, 0, sizeof(ps));
+        ps.B = Bt; ps.H = lay.H; ps.Hp = lay.Hp; ps.D = lay.D; ps.W = lay.W;
+        ps.AVW = lay.AVW;
+        CellFwdArgs pc;
+        memset(&pc, 0, sizeof(pc));
+        pc.B = Bt; pc.Hn = lay.Hn;
+        split64 = pcm_stack_fwd_is_mfma(ps) && pcm_cell_fwd_tile(pc) == 64;
+    }
     if (lay.use_stack && !fuse) {
         StackFwdArgs s;
+        s.top_only = split64 ? 1 : 0;
         s.htop = sb.h_prev[lay.L - 1] + oH;
         s.S_prev = sb.S_prev + oS; s.S_new = sb.S_new + oS;
         s.ctrl_w = w->ctrl_w; s.ctrl_b = w->ctrl_b;
@@ -413,10 +437,11 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
             c.xt_av = sb.av + oAV; c.xt_xtop = sb.xtop + oX;
             c.xt_W = lay.W; c.xt_D = lay.D; c.xt_AVW = lay.AVW;
         }
-        if (fuse && l == lay.L - 1) {
+        if ((fuse || split64) && l == lay.L - 1) {
             c.su_S = sb.S_prev + oS; c.su_Snew = sb.S_new + oS;
             c.su_av = sb.av + oAV;
-            c.su_nbt = (Bt + 31) / 32; c.su_rows = 2;
+            c.su_nbt = fuse ? (Bt + 31) / 32 : (Bt + 63) / 64;
+            c.su_rows = fuse ? 2 : split64_rows;
             c.su_D = lay.D; c.su_W = lay.W; c.su_AVW = lay.AVW;
         }
         if (l == lay.L - 1 && have_part) {

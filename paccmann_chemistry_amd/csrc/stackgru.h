@@ -136,8 +136,14 @@ struct StackFwdArgs {
     // are computed here
     const float *cs_part;
     int cs_parts;
+    // top_only (large-batch kernel): controls, push value and the new stack TOP
+    // only -- the update of the whole stack rides in the top layer's forward-cell
+    // launch of the same step (CellFwdArgs::su_*), off the critical chain
+    int top_only;
 };
 int pcm_launch_stack_fwd(const StackFwdArgs &a, hipStream_t stream);
+// true if that launch goes to the large-batch kernel, the one that takes top_only
+bool pcm_stack_fwd_is_mfma(const StackFwdArgs &a);
 // The stack kernels stage whole [D, W] stacks in LDS: PCM_OK if one batch row
 // fits the dynamic LDS of a block, else PCM_EINVAL with the limit in the
 // message.  Checked once per call, before anything is launched.

@@ -802,6 +802,12 @@ template <bool BF16>
 __global__ __launch_bounds__(512, 4) void gru_cell_fwd64_kernel(CellFwdArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * LSTAGE];
     const int tid = threadIdx.x;
+    if (a.su_S && (int)blockIdx.y >= a.su_nbt) {
+        // extra blocks: the step's stack update, off the critical path
+        const int id = ((int)blockIdx.y - a.su_nbt) * gridDim.x + blockIdx.x;
+        cell_fwd_stack_update(a, id * a.su_rows, tid);
+        return;
+    }
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j0 = blockIdx.x * LN;
@@ -1505,8 +1511,9 @@ __global__ __launch_bounds__(512) void stack_step_fwd_mfma_kernel(StackFwdArgs a
         if (b0 + r < a.B)
             a.av[(long long)(b0 + r) * a.AVW + o] = o < NO ? cu[r][o] : 0.f;
     }
-    // the update, four consecutive elements per thread (DW % 4 == 0)
-    const int nq = DW >> 2;
+    // the update, four consecutive elements per thread (DW % 4 == 0); top_only:
+    // the quads that hold row 0 only (the rest rides in the top cell's launch)
+    const int nq = a.top_only ? (W + 3) >> 2 : DW >> 2;
     const float inv_nq = 1.0f / (float)nq;
 #pragma unroll 4
     for (int idx = tid; idx < MROWS * nq; idx += 512) {
@@ -1537,7 +1544,7 @@ __global__ __launch_bounds__(512) void stack_step_fwd_mfma_kernel(StackFwdArgs a
                                   __fmul_rn(c[1], dn));
             }
         }
-        *(f32x4 *)(a.S_new + (long long)b * DW + q * 4) = nv;
+        if (!a.top_only) *(f32x4 *)(a.S_new + (long long)b * DW + q * 4) = nv;
         float *xt = a.xtop + (long long)b * a.Wp;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1725,13 +1732,20 @@ int pcm_cell_fwd_ctrl_partials(const CellFwdArgs &a) {
 int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
     const int nbt = (a.B + CM - 1) / CM;
     const int tile = cell_fwd_tile(a);
-    PCM_REQUIRE(tile == 32 || (!a.su_S && !a.xt_part), PCM_EINVAL,
-                "cell_fwd: the fused stack step needs the 32 x 32 tile");
+    PCM_REQUIRE(tile == 32 || (!a.xt_part && (tile == 64 || !a.su_S)), PCM_EINVAL,
+                "cell_fwd: the fused stack step needs the 32 x 32 tile (the "
+                "update alone may ride with the 64 x 64 tile)");
     PCM_REQUIRE(!a.cs_part || pcm_cell_fwd_ctrl_partials(a) > 0, PCM_EINVAL,
                 "cell_fwd: control partials asked of a launch that cannot "
                 "write them (tile %d, H %d, Hn %d)", tile, a.H, a.Hn);
     if (tile == 64) {
         dim3 grid(a.Hn / LN, (a.B + LM - 1) / LM);
+        if (a.su_S) {
+            PCM_REQUIRE(a.su_nbt == (int)grid.y && a.su_rows > 0, PCM_EINVAL,
+                        "cell_fwd: bad stack-update arguments");
+            const int ublocks = (a.B + a.su_rows - 1) / a.su_rows;
+            grid.y += (ublocks + grid.x - 1) / grid.x;
+        }
         if (g_pcm_matmul_bf16)
             PCM_LAUNCH(gru_cell_fwd64_kernel<true>, grid, dim3(512), 0, stream, a);
         else
@@ -1786,6 +1800,22 @@ int pcm_stack_fwd_check(int D, int W, int H, int AVW) {
     return PCM_OK;
 }
 
+static bool stack_fwd_mfma_shape(const StackFwdArgs &a, int mfma_rows) {
+    return a.B >= mfma_rows && (a.H % 32) == 0 && (a.Hp % 4) == 0 &&
+           3 + a.W <= 64 && ((a.D * a.W) & 3) == 0 && a.AVW <= 64;
+}
+static int stack_fwd_mfma_rows() {
+    // large batches: 16 rows per block with the dot products on MFMA
+    static const int mfma_rows = [] {
+        const char *e = getenv("PCM_STACK_MFMA");   // rows from which it is used
+        return e ? atoi(e) : 4096;
+    }();
+    return mfma_rows;
+}
+bool pcm_stack_fwd_is_mfma(const StackFwdArgs &a) {
+    return stack_fwd_mfma_shape(a, stack_fwd_mfma_rows());
+}
+
 int pcm_launch_stack_fwd(const StackFwdArgs &a, hipStream_t stream) {
     const size_t row_bytes = stack_fwd_row_bytes(a.D, a.W, a.H, a.AVW);
     int rc = pcm_stack_fwd_check(a.D, a.W, a.H, a.AVW);
@@ -1801,13 +1831,10 @@ int pcm_launch_stack_fwd(const StackFwdArgs &a, hipStream_t stream) {
                                         dev);
         return n;
     }();
-    // large batches: 16 rows per block with the dot products on MFMA
-    static const int mfma_rows = [] {
-        const char *e = getenv("PCM_STACK_MFMA");   // rows from which it is used
-        return e ? atoi(e) : 4096;
-    }();
-    if (a.B >= mfma_rows && (a.H % 32) == 0 && (a.Hp % 4) == 0 &&
-        3 + a.W <= 64 && ((a.D * a.W) & 3) == 0 && a.AVW <= 64) {
+    const int mfma_rows = stack_fwd_mfma_rows();
+    PCM_REQUIRE(!a.top_only || stack_fwd_mfma_shape(a, mfma_rows), PCM_EINVAL,
+                "stack step: top_only needs the large-batch kernel");
+    if (stack_fwd_mfma_shape(a, mfma_rows)) {
         static const int mrows = [] {
             const char *e = getenv("PCM_STACK_MROWS");
             const int v = e ? atoi(e) : 8;

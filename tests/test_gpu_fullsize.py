@@ -497,6 +497,7 @@ def test_large_stack_gradients_and_limit():
     {'PCM_FUSE_STACK': '0'},
     {'PCM_ROW_SKIP': '0'},
     {'PCM_STACK_SPLIT': '0'},
+    {'PCM_STACK_SPLIT64': '8'},
 ])
 def test_opt_in_recurrence_variants(env):
     """The forms of the recurrence that are built but not the default (measured
@@ -509,7 +510,9 @@ def test_opt_in_recurrence_variants(env):
     packed-mode weight-gradient reduction over all rows, zeros included;
     PCM_STACK_SPLIT=0 the stack adjoint as one launch on the chain (the
     default since round 3 splits it: bulk as rider blocks of the layer-0
-    reverse cell, stack-top terms + gate gradient on the chain).  The switches are read once per process, hence a
+    reverse cell, stack-top terms + gate gradient on the chain);
+    PCM_STACK_SPLIT64=8 the large-batch forward stack step as a top-only
+    launch + update riders in the 64 x 64 top cell (measured slower).  The switches are read once per process, hence a
     child process: the full-size training step (every gradient against the
     oracle, with and without dropout), the B=4096 rows and the packed / padded
     data-parallel shard test."""
