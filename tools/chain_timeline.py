@@ -9,7 +9,8 @@ for r in rows:
     m = re.search(r'(\w+_kernel)(<[^>]*>)?', r['Kernel_Name'])
     r['n'] = (m.group(1) + (m.group(2) or '')) if m else r['Kernel_Name'][:40]
 rows.sort(key=lambda r: r['s'])
-ce = [i for i, r in enumerate(rows) if r['n'].startswith('softmax_ce_kernel')]
+ce = [i for i, r in enumerate(rows)
+      if r['n'].startswith(('softmax_ce_kernel', 'output_ce_kernel'))]
 lo = ce[-2] if len(ce) > 1 else 0
 seg = rows[lo:ce[-1]] if len(ce) > 1 else rows
 # keep the last training step: from the previous step's CE to this one's is
@@ -34,7 +35,15 @@ for q, rs in byq.items():
         busy = sum(r['e'] - r['s'] for r in rs) / 1e6
         print('queue %s: %d kernels, busy %.2f ms, gap median %.2f us, mean %.2f us, sum of gaps %.2f ms' % (
             q, len(rs), busy, gaps[len(gaps) // 2], sum(gaps) / len(gaps), sum(gaps) / 1e3))
-for name in ('stack_step_fwd_kernel', 'stack_bwd_kernel'):
+# step markers: the forward stack step (or, with it fused into the cells, the
+# layer-0 cell's XT instantiation), the stack adjoint (fused or its finish launch)
+FWD_MARK = ('stack_step_fwd_kernel'
+            if sum(r['n'].startswith('stack_step_fwd_kernel') for r in seg) > 100
+            else 'gru_cell_fwd_kernel<false, true>')
+BWD_MARK = ('stack_bwd_finish_kernel'
+            if any(r['n'].startswith('stack_bwd_finish_kernel') for r in seg)
+            else 'stack_bwd_kernel')
+for name in (FWD_MARK, BWD_MARK):
     for q, rs in byq.items():
         ks = [r for r in rs if r['n'].startswith(name)]
         if len(ks) > 10:
@@ -49,5 +58,5 @@ def listing(name, skip, count):
     print('--- three steps from the %dth %s' % (skip, name))
     for r in seg[a:b + 1]:
         print('  q%-3s %-40s start %8.2f us  dur %6.2f us' % (r['Queue_Id'], r['n'][:40], (r['s'] - base) / 1e3, (r['e'] - r['s']) / 1e3))
-listing('stack_step_fwd_kernel', 40, 3)
-listing('stack_bwd_kernel', 40, 3)
+listing(FWD_MARK, 40, 3)
+listing(BWD_MARK, 40, 3)
