@@ -10,6 +10,9 @@
 // s_memtime-based wall_clock64 (100 MHz); the host prints the slowest wave of
 // each role for: MFMA alone, other alone, both at once, and (mode 3) the same
 // wave alternating one MFMA with independent instructions of the other kind.
+//
+// build: hipcc -O3 --offload-arch=gfx950 tools/mfma_valu_overlap.hip -o tools/bin/mfma_valu_overlap
+// result of this round: profiles/r03_mfma_valu_overlap.txt
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
