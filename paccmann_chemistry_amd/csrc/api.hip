@@ -243,6 +243,7 @@ int pcm_sg_layout(const pcm_dims *d, int steps, int training, int dropout,
             take(off, (size_t)(o->xtop_per_step ? steps : 1) * o->B * o->Wp);
     }
     o->off_sync = take(off, persist ? pcm_persist_fwd_sync_words() : 0);
+    o->off_hraw = take(off, (o->use_stack && o->L >= 2) ? (size_t)o->B * 3 * o->Hn : 0);
     o->off_cspart =
         take(off, o->use_stack ? (size_t)o->B * (o->Hn / 16) * 64 : 0);
     o->off_cpre = take(off, persist ? (size_t)steps * o->B * 64 : 0);
@@ -324,7 +325,7 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
                         const int32_t *lengths, int t, float drop_p,
                         uint64_t seed, int32_t *status, hipStream_t st,
                         int rows = -1, int b0 = 0, float *cs_part = nullptr,
-                        int *have_part = nullptr) {
+                        int *have_part = nullptr, float *hraw = nullptr) {
     // cs_part / have_part: the top layer's forward cell may leave partial sums
     // of the next step's stack controls (see CellFwdArgs); *have_part says, on
     // entry, that the previous step left them for (at least) these rows, and on
@@ -429,6 +430,31 @@ static int enqueue_step(const SGLayout &lay, const pcm_stackgru_params *w,
         c.seed = seed;
         c.cs_ctrl_w = c.cs_push_w = nullptr; c.cs_part = nullptr; c.cs_W = 0;
         c.xt_part = nullptr; c.su_S = nullptr;
+        c.hz_raw = nullptr; c.hraw = nullptr; c.hz_hprev = c.hz_wpack = nullptr;
+        c.hz_nbt = c.hz_Kp = c.hz_kx = 0;
+        // Opt-in (PCM_FWD_HOIST=1): layer 1's hidden-side product -- it only needs
+        // h1_{t-1} -- rides as 256 extra blocks in layer 0's fused launch, whose
+        // own blocks spend their first 4 us in the stack prologue with the matrix
+        // pipes idle.  Measured at batch 512: the top cell 19.2 -> 14.3 us, but
+        // the layer-0 launch 18.2 -> 24.5 us: the co-resident blocks do not hide
+        // in the prologue, they stretch it (25.13 against 25.05 ms per step).
+        static const bool hoist_on = [] {
+            const char *e = getenv("PCM_FWD_HOIST");
+            return e && atoi(e) != 0;
+        }();
+        const bool hoist = fuse && hoist_on && hraw && lay.L >= 2;
+        if (hoist && l == 0) {
+            c.hz_hprev = sb.h_prev[1] + oH;
+            c.hz_wpack = wpack[1];
+            c.hz_raw = hraw + (size_t)b0 * 3 * lay.Hn;
+            c.hz_nbt = (Bt + 31) / 32;
+            c.hz_Kp = lay.Kp[1];
+            c.hz_kx = lay.Kxp[1] / 64;
+        }
+        if (hoist && l == 1) {
+            c.hraw = hraw + (size_t)b0 * 3 * lay.Hn;
+            c.nh_chunks = 0;
+        }
         if (fuse && l == 0) {
             c.xt_part = cs_part + (size_t)b0 * (lay.Hn / 16) * 64;
             c.xt_parts = lay.Hn / 32;
@@ -809,7 +835,9 @@ int pcm_stackgru_forward(const pcm_dims *dims,
             rc = enqueue_step(lay, weights, sv + lay.off_tokg, wpack, bpack, sb,
                               lengths, t, dropout_p, seed, status,
                               c == 0 ? st : cs->stream, n, b0, cs_part,
-                              &have_part[c]);
+                              &have_part[c],
+                              lay.L >= 2 && lay.use_stack ? sv + lay.off_hraw
+                                                          : nullptr);
             if (rc) return rc;
         }
     }

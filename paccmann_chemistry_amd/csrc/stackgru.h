@@ -24,6 +24,7 @@ struct SGLayout {
                        // persistent kernel, which hands it over at fresh
                        // addresses), else one B x Wp slot
     size_t off_sync;   // hand-off counters of the persistent kernel (words)
+    size_t off_hraw;   // B x 3 x Hn: hoisted hidden-side sums of layer 1 (CellFwdArgs::hz_raw)
     size_t off_cspart; // B x (Hn / 32) x 64: partial control / push sums that
                        // the top layer's forward cell leaves for the next stack step
     size_t off_cpre;   // T x B x 64: stack control / push pre-activations the
@@ -113,6 +114,18 @@ struct CellFwdArgs {
     const float *su_S, *su_av;
     float *su_Snew;
     int su_nbt, su_rows, su_D, su_W, su_AVW;
+    // Hidden-side product of the layer ABOVE, hoisted into this (layer 0, fused)
+    // launch as extra blocks (blockIdx.y >= hz_nbt; hz_raw == null: none): it
+    // only needs that layer's previous hidden state, and this launch's own blocks
+    // spend their first microseconds in the stack prologue with the matrix pipes
+    // idle.  hz_raw[b][3][Hn]: the raw r, z, n(hidden) sums of h_prev . W_hh^T.
+    const float *hz_hprev;   // [B, Hp] previous hidden state of the layer above
+    const float *hz_wpack;   // its packed weights [3*Hn, hz_Kp]
+    float *hz_raw;
+    int hz_nbt, hz_Kp, hz_kx;   // hz_kx: 64-wide chunks of its input side (skipped)
+    // ... and the launch of the layer above then runs its input side only
+    // (nh_chunks = 0) and adds these sums in the epilogue
+    const float *hraw;       // [B][3][Hn] or null
 };
 int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream);
 // tile the forward cell launcher picks for `a` (16, 32 or 64); the fused stack

@@ -138,6 +138,10 @@ __device__ __forceinline__ void cell_fwd_element(const CellFwdArgs &a, int b,
 
 // Cross-wave reduction of the four K-slice partials through LDS, then the GRU
 // cell epilogue for the 32 x 32 tile (two outputs per thread).
+// hz: the hoisted hidden-side sums (r, z, n) of this thread's two outputs
+// (CellFwdArgs::hraw; zeros when the launch computed them itself).  raw_out: an
+// extra block of a layer-0 launch (CellFwdArgs::hz_raw) -- the reduced r, z,
+// n(hidden) sums are stored as they are and nothing else happens.
 __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
                                               const f32x16 &acc_r,
                                               const f32x16 &acc_z,
@@ -145,7 +149,9 @@ __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
                                               const f32x16 &acc_nh, int tid,
                                               int wave, int lrow, int lh,
                                               int j0, int b0,
-                                              const f32x4 (&wf)[2]) {
+                                              const f32x4 (&wf)[2],
+                                              const float (&hz)[2][3],
+                                              bool raw_out = false) {
     // cross-wave reduction of the 4 partial tiles through LDS
     __syncthreads();
     float *red = lds;  // [wave][tile][32][32]
@@ -180,8 +186,17 @@ __device__ __forceinline__ void cell_fwd_tail(const CellFwdArgs &a, float *lds,
         }
         live[q] = b < a.B && j < H;
         out[q].hn = 0.f;
+        if (raw_out) {
+            if (live[q]) {
+                float *dst = a.hz_raw + (long long)b * 3 * a.Hn + j;
+                dst[0] = s[0]; dst[a.Hn] = s[1]; dst[2 * a.Hn] = s[3];
+            }
+            continue;
+        }
+        s[0] += hz[q][0]; s[1] += hz[q][1]; s[3] += hz[q][2];
         if (live[q]) out[q] = cell_fwd_math(a, b, j, s);
     }
+    if (raw_out) return;
     f32x4 part = {0.f, 0.f, 0.f, 0.f};
     if (a.cs_part) {
         // Top layer with a stack: this tile's share of the next stack step's
@@ -416,8 +431,12 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
         return;
     }
     const int j0 = blockIdx.x * CN;
-    const int b0 = blockIdx.y * CM;
-    const int nchunks = a.nx_chunks + a.nh_chunks;
+    // role H (block-uniform; layer-0 launches only): an extra block computing the
+    // hidden-side sums of the layer above for row tile blockIdx.y - hz_nbt
+    const bool role_h = XT && a.hz_raw && (int)blockIdx.y >= a.hz_nbt;
+    const int b0 = (role_h ? (int)blockIdx.y - a.hz_nbt : (int)blockIdx.y) * CM;
+    const int nx_chunks = role_h ? 0 : a.nx_chunks;
+    const int nchunks = nx_chunks + (role_h ? a.Hp / CK : a.nh_chunks);
     const int last = nchunks - 1;
     const int lrow = lane & 31, lh = lane >> 5;
 
@@ -428,11 +447,27 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
     }
     f32x4 wf[2];
     cell_fwd_ctrl_frags(a, wave, lane, j0, wf);
+    // the hoisted hidden-side sums of this thread's two outputs, requested now
+    float hz[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    if (a.hraw) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = tid + 512 * q;
+            const int b = min(b0 + (e >> 5), a.B - 1), j = min(j0 + (e & 31), a.Hn - 1);
+            const float *src = a.hraw + (long long)b * 3 * a.Hn + j;
+            hz[q][0] = src[0]; hz[q][1] = src[a.Hn]; hz[q][2] = src[2 * a.Hn];
+        }
+    }
     if (wave >= 4) {
         // loaders: same lane -> (row, swizzled granule) map as above
         const int lw = wave - 4;
-        const char *xb = (const char *)a.xin, *hb = (const char *)a.hprev;
-        const char *wb = (const char *)a.wpack;
+        const char *xb = (const char *)a.xin;
+        const char *hb = (const char *)(role_h ? a.hz_hprev : a.hprev);
+        // role H: the weights of the layer above, from the first chunk of their
+        // hidden side on
+        const char *wb = role_h ? (const char *)a.hz_wpack + a.hz_kx * (CK * 4)
+                                : (const char *)a.wpack;
+        const int Kp = role_h ? a.hz_Kp : a.Kp;
         uint32_t off0[8], off1[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -444,7 +479,7 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
                 off1[i] = (uint32_t)(b * a.Hp + g * 4) * 4u;
             } else {
                 const int wr = row - CM, gate = wr >> 5, jj = wr & 31;
-                off0[i] = (uint32_t)((gate * a.Hn + j0 + jj) * a.Kp + g * 4) * 4u;
+                off0[i] = (uint32_t)((gate * a.Hn + j0 + jj) * Kp + g * 4) * 4u;
                 off1[i] = 0;
             }
         }
@@ -455,11 +490,11 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
             const uint32_t dst =
                 lds0 + ((cc % CNSTAGE) * GSTAGE + lw * 8 * 256) * 4u;
             if (lw == 0) {
-                if (c < a.nx_chunks) {
+                if (c < nx_chunks) {
                     // (fused stack step: the prologue writes these rows)
                     if (!XT) glds8(xb + c * (CK * 4), off0, dst);
                 } else {
-                    glds8(hb + (c - a.nx_chunks) * (CK * 4), off1, dst);
+                    glds8(hb + (c - nx_chunks) * (CK * 4), off1, dst);
                 }
             } else {
                 glds8(wb + c * (CK * 4), off0, dst);
@@ -467,7 +502,7 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
         };
         issue(0); issue(1);
         if constexpr (XT)
-            cell_fwd_xtop_prologue(a, lds, tid, b0, blockIdx.x);
+            if (!role_h) cell_fwd_xtop_prologue(a, lds, tid, b0, blockIdx.x);
         for (int k = 0; k < nchunks; ++k) {
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // chunk k landed
             raw_barrier();   // A_k: the consumers may read chunk k
@@ -477,7 +512,7 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
         if constexpr (XT)
-            cell_fwd_xtop_prologue(a, lds, tid, b0, blockIdx.x);
+            if (!role_h) cell_fwd_xtop_prologue(a, lds, tid, b0, blockIdx.x);
         int slot[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -521,11 +556,11 @@ __global__ __launch_bounds__(512, 4) void gru_cell_fwd_kernel(CellFwdArgs a) {
                         fa[s][e], fn[s][e], acc_n, 0, 0, 0);
                 }
         };
-        for (int c = 0; c < a.nx_chunks; ++c) chunk(c, acc_ni);
-        for (int c = a.nx_chunks; c < nchunks; ++c) chunk(c, acc_nh);
+        for (int c = 0; c < nx_chunks; ++c) chunk(c, acc_ni);
+        for (int c = nx_chunks; c < nchunks; ++c) chunk(c, acc_nh);
     }
     cell_fwd_tail(a, lds, acc_r, acc_z, acc_ni, acc_nh, tid, wave, lrow, lh, j0,
-                  b0, wf);
+                  b0, wf, hz, role_h);
 }
 
 
@@ -1765,6 +1800,10 @@ int pcm_launch_cell_fwd(const CellFwdArgs &a, hipStream_t stream) {
             const int ublocks = (a.B + a.su_rows - 1) / a.su_rows;
             grid.y += (ublocks + grid.x - 1) / grid.x;
         }
+        PCM_REQUIRE(!a.hz_raw || (a.xt_part && !a.su_S && a.hz_nbt == nbt),
+                    PCM_EINVAL, "cell_fwd: the hoisted hidden-side product rides "
+                    "in the fused layer-0 launch only");
+        if (a.hz_raw) grid.y += nbt;
         if (a.xt_part) {
             if (g_pcm_matmul_bf16)
                 PCM_LAUNCH((gru_cell_fwd_kernel<true, true>), grid, dim3(512), 0,

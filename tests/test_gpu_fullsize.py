@@ -498,6 +498,7 @@ def test_large_stack_gradients_and_limit():
     {'PCM_ROW_SKIP': '0'},
     {'PCM_STACK_SPLIT': '0'},
     {'PCM_STACK_SPLIT64': '8'},
+    {'PCM_FWD_HOIST': '1'},
 ])
 def test_opt_in_recurrence_variants(env):
     """The forms of the recurrence that are built but not the default (measured
@@ -512,7 +513,9 @@ def test_opt_in_recurrence_variants(env):
     default since round 3 splits it: bulk as rider blocks of the layer-0
     reverse cell, stack-top terms + gate gradient on the chain);
     PCM_STACK_SPLIT64=8 the large-batch forward stack step as a top-only
-    launch + update riders in the 64 x 64 top cell (measured slower).  The switches are read once per process, hence a
+    launch + update riders in the 64 x 64 top cell (measured slower);
+    PCM_FWD_HOIST=1 layer 1's hidden-side product as extra blocks of layer
+    0's fused launch (measured level to slower).  The switches are read once per process, hence a
     child process: the full-size training step (every gradient against the
     oracle, with and without dropout), the B=4096 rows and the packed / padded
     data-parallel shard test."""
