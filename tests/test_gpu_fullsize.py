@@ -497,8 +497,9 @@ def test_large_stack_gradients_and_limit():
     {'PCM_FUSE_STACK': '0'},
     {'PCM_ROW_SKIP': '0'},
     {'PCM_STACK_SPLIT': '0'},
-    {'PCM_STACK_SPLIT64': '8'},
-    {'PCM_FWD_HOIST': '1'},
+    # (switches that only touch one shape run the tests of that shape)
+    {'PCM_STACK_SPLIT64': '8', '-k': 'batch_4096'},
+    {'PCM_FWD_HOIST': '1', '-k': 'full_size_training or vae_config_golden'},
 ])
 def test_opt_in_recurrence_variants(env):
     """The forms of the recurrence that are built but not the default (measured
@@ -523,11 +524,13 @@ def test_opt_in_recurrence_variants(env):
     import subprocess
     import sys
     from conftest import ROOT
+    env = dict(env)
+    select = env.pop('-k', 'full_size_training or batch_4096 or shards_sum or '
+                           'determinism or vae_config_golden or '
+                           'packed_training_step')
     cmd = [sys.executable, '-m', 'pytest', '-x', '-q', '-p', 'no:cacheprovider',
            os.path.join(ROOT, 'tests', 'test_gpu_fullsize.py'),
-           os.path.join(ROOT, 'tests', 'test_gpu_parity.py'), '-k',
-           'full_size_training or batch_4096 or shards_sum or determinism or '
-           'vae_config_golden or packed_training_step']
+           os.path.join(ROOT, 'tests', 'test_gpu_parity.py'), '-k', select]
     res = subprocess.run(cmd, env=dict(os.environ, **env), cwd=ROOT,
                          capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
