@@ -266,8 +266,8 @@ struct CellBwdArgs {
     StackBulkArgs rider;
 };
 int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream);
-// true if that launch can carry rider blocks (narrow fp32 tiles, no XPART, the
-// stack rows fit the cell's LDS)
+// true if that launch can carry rider blocks (narrow tiles, the stack rows fit
+// the cell's LDS)
 bool pcm_cell_bwd_takes_rider(const CellBwdArgs &a, int D, int W);
 // how many partials (stride xpart_stride, to be summed in order) that launch
 // leaves dx in; 1 = the plain result

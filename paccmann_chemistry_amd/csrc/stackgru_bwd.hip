@@ -1006,8 +1006,7 @@ int pcm_cell_bwd_xparts(const CellBwdArgs &a) {
 bool pcm_cell_bwd_takes_rider(const CellBwdArgs &a, int D, int W) {
     const int DWp = (D * W + 3) & ~3;
     // (the narrow tile's three stages: 3 * (32 + 32) * 64 floats)
-    return !g_pcm_matmul_bf16 && bwd_narrow(a) &&
-           2 * DWp + 32 <= 3 * (BCM + 32) * BCK;
+    return bwd_narrow(a) && 2 * DWp + 32 <= 3 * (BCM + 32) * BCK;
 }
 
 int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream) {
@@ -1030,12 +1029,20 @@ int pcm_launch_cell_bwd(const CellBwdArgs &a, hipStream_t stream) {
         b.ncell = (int)grid.x;
         b.rider_per = per;
         const dim3 rgrid(grid.x + (a.rider_rows + per - 1) / per);
-        if (xpart)
+        if (g_pcm_matmul_bf16) {
+            if (xpart)
+                PCM_LAUNCH((gru_cell_bwd_kernel<32, 3, true, true, true>), rgrid,
+                           dim3(512), 0, stream, b);
+            else
+                PCM_LAUNCH((gru_cell_bwd_kernel<32, 3, false, true, true>), rgrid,
+                           dim3(512), 0, stream, b);
+        } else if (xpart) {
             PCM_LAUNCH((gru_cell_bwd_kernel<32, 3, true, false, true>), rgrid,
                        dim3(512), 0, stream, b);
-        else
+        } else {
             PCM_LAUNCH((gru_cell_bwd_kernel<32, 3, false, false, true>), rgrid,
                        dim3(512), 0, stream, b);
+        }
         return 0;
     }
     if (g_pcm_matmul_bf16) {
