@@ -500,6 +500,12 @@ def test_large_stack_gradients_and_limit():
     # (switches that only touch one shape run the tests of that shape)
     {'PCM_STACK_SPLIT64': '8', '-k': 'batch_4096'},
     {'PCM_FWD_HOIST': '1', '-k': 'full_size_training or vae_config_golden'},
+    # the measured-slower placements of the split stack adjoint: half the rider
+    # rows in the top layer's launch, two rows per rider block, four rows per
+    # finish block
+    {'PCM_STACK_RIDER_TOP': '50', 'PCM_STACK_RIDER_PER': '2',
+     'PCM_STACK_FINISH_ROWS': '4',
+     '-k': 'full_size_training or packed_training_step'},
 ])
 def test_opt_in_recurrence_variants(env):
     """The forms of the recurrence that are built but not the default (measured
